@@ -1,0 +1,230 @@
+"""eagle-in-llama.cpp_amd -- MI355X-native EAGLE speculative-decoding path for llama.cpp.
+
+The product is two shared libraries built by ``build.py`` (hipcc, gfx950):
+
+* ``lib/libggml-mi355x.so``  -- the ggml backend plugin (C ABI in ``include/ggml_mi355x.h``), loaded by a
+  reference binary through ``GGML_BACKEND_PATH`` or by our own host below;
+* ``lib/libeagle_host.so``   -- the C++ host side above that ABI (graph builders mirroring
+  ``build_llama``/``build_eagle``, KV-cell bookkeeping, the speculative drivers), driven from Python
+  through the plain-C functions in ``host/capi.cpp``.
+
+This module is only glue: ctypes bindings, paths, and a loud failure when the HIP plugin is missing.
+Because the directory name is not a valid identifier, import it with :func:`load_package` from
+``__graft_entry__`` (or ``importlib``); inside Python it is known as ``eagle_amd``.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "lib")
+PLUGIN_PATH = os.path.join(LIB, "libggml-mi355x.so")
+HOST_PATH = os.path.join(LIB, "libeagle_host.so")
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+REF_GGML_PATH = os.path.join(REF_DIR, "libggml-ref.so")
+REF_GGML_SCALAR_PATH = os.path.join(REF_DIR, "libggml-ref-scalar.so")
+
+# ggml enums (include/ggml_abi.h)
+F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, I32, BF16 = 0, 1, 2, 8, 12, 13, 14, 26, 30
+OP_ADD, OP_SUB, OP_MUL, OP_DIV = 2, 5, 6, 7
+UNARY = dict(abs=0, sgn=1, neg=2, step=3, tanh=4, elu=5, relu=6, sigmoid=7, gelu=8, gelu_quick=9, silu=10,
+             hardswish=11, hardsigmoid=12, exp=13)
+TYPE_TRAITS = {F32: (1, 4), F16: (1, 2), BF16: (1, 2), I32: (1, 4), Q4_0: (32, 18), Q8_0: (32, 34),
+               Q4_K: (256, 144), Q5_K: (256, 176), Q6_K: (256, 210)}
+TYPE_NAMES = {F32: "f32", F16: "f16", BF16: "bf16", I32: "i32", Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K", Q6_K: "q6_K"}
+USAGE_ANY, USAGE_WEIGHTS, USAGE_COMPUTE = 0, 1, 2
+
+
+class PluginMissing(RuntimeError):
+    pass
+
+
+def require_plugin():
+    """The product path never falls back to a CPU implementation: no plugin => error."""
+    if not os.path.exists(PLUGIN_PATH):
+        raise PluginMissing(f"{PLUGIN_PATH} not built -- run `python {HERE}/build.py` (hipcc, gfx950)")
+    return PLUGIN_PATH
+
+
+_host = None
+
+
+def host():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_PATH):
+            raise PluginMissing(f"{HOST_PATH} not built -- run `python {HERE}/build.py`")
+        h = C.CDLL(HOST_PATH)
+        vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+        sig = {
+            "eh_backend_load": (vp, [C.c_char_p, C.c_char_p, i32, C.c_char_p, i32]),
+            "eh_backend_free": (None, [vp]), "eh_backend_name": (C.c_char_p, [vp]),
+            "eh_backend_description": (C.c_char_p, [vp]),
+            "eh_backend_set_threads": (None, [vp, i32]), "eh_backend_is_host": (i32, [vp]),
+            "eh_ctx_new": (vp, [vp, i32]), "eh_ctx_free": (None, [vp]),
+            "eh_tensor_new": (vp, [vp, i32, i64, i64, i64, i64]),
+            "eh_tensor_set_name": (None, [vp, vp, C.c_char_p]), "eh_tensor_set_flags": (None, [vp, i32]),
+            "eh_view": (vp, [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), i64]),
+            "eh_reshape": (vp, [vp, vp, i64, i64, i64, i64]), "eh_permute": (vp, [vp, vp, i32, i32, i32, i32]),
+            "eh_transpose": (vp, [vp, vp]), "eh_cont": (vp, [vp, vp]), "eh_cpy": (vp, [vp, vp, vp]),
+            "eh_mul_mat": (vp, [vp, vp, vp]), "eh_rms_norm": (vp, [vp, vp, f32]), "eh_bin": (vp, [vp, i32, vp, vp]),
+            "eh_unary": (vp, [vp, vp, i32]), "eh_scale": (vp, [vp, vp, f32]), "eh_concat": (vp, [vp, vp, vp, i32]),
+            "eh_get_rows": (vp, [vp, vp, vp]),
+            "eh_rope": (vp, [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, f32]),
+            "eh_soft_max": (vp, [vp, vp, vp, f32, f32]),
+            "eh_alloc": (i32, [vp]), "eh_compute": (i32, [vp]),
+            "eh_set": (None, [vp, vp, vp, i64, i64]), "eh_get": (None, [vp, vp, vp, i64, i64]),
+            "eh_supports": (i32, [vp, vp]), "eh_nbytes": (i64, [vp]), "eh_shape": (None, [vp, C.POINTER(i64), C.POINTER(i64)]),
+            "eh_type": (i32, [vp]), "eh_n_nodes": (i32, [vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        _host = h
+    return _host
+
+
+class Backend:
+    """A loaded ggml-ABI backend: our plugin (`Backend.mi355x()`) or the reference CPU backend (`Backend.reference_cpu()`)."""
+
+    def __init__(self, path, entry, device=0, threads=None):
+        err = C.create_string_buffer(512)
+        self.h = host().eh_backend_load(path.encode(), entry.encode(), device, err, 512)
+        if not self.h:
+            raise RuntimeError(f"cannot load backend {path}: {err.value.decode()}")
+        self.path = path
+        if threads:
+            host().eh_backend_set_threads(self.h, threads)
+
+    @staticmethod
+    def mi355x(device=0):
+        return Backend(require_plugin(), "ggml_backend_init", device)
+
+    @staticmethod
+    def reference_cpu(threads=None, scalar=False):
+        p = REF_GGML_SCALAR_PATH if scalar else REF_GGML_PATH
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"{p} not built (make -C oracle ref; needs /root/reference)")
+        return Backend(p, "ggml_backend_cpu_reg", 0, threads or (os.cpu_count() or 4))
+
+    @property
+    def name(self):
+        return host().eh_backend_name(self.h).decode()
+
+    @property
+    def description(self):
+        return host().eh_backend_description(self.h).decode()
+
+
+class Graph:
+    """One graph on one backend: create tensors/ops, `alloc()`, `set()`, `compute()`, `get()`."""
+
+    def __init__(self, backend, usage=USAGE_ANY):
+        self.be = backend
+        self.h = host().eh_ctx_new(backend.h, usage)
+        self._keep = []
+
+    def __del__(self):
+        try:
+            if self.h:
+                host().eh_ctx_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def tensor(self, dtype, *ne, name=None):
+        ne = list(ne) + [1] * (4 - len(ne))
+        t = host().eh_tensor_new(self.h, dtype, *ne)
+        if name:
+            host().eh_tensor_set_name(self.h, t, name.encode())
+        return t
+
+    def view(self, a, ne, nb, offset=0):
+        nd = len(ne)
+        ne_a = (C.c_int64 * 4)(*(list(ne) + [1] * (4 - nd)))
+        nb_a = (C.c_int64 * 4)(*(list(nb) + [0] * (4 - len(nb))))
+        return host().eh_view(self.h, a, nd, ne_a, nb_a, offset)
+
+    def reshape(self, a, *ne):
+        ne = list(ne) + [1] * (4 - len(ne))
+        return host().eh_reshape(self.h, a, *ne)
+
+    def permute(self, a, *ax):
+        return host().eh_permute(self.h, a, *ax)
+
+    def transpose(self, a):
+        return host().eh_transpose(self.h, a)
+
+    def cont(self, a):
+        return host().eh_cont(self.h, a)
+
+    def cpy(self, a, b):
+        return host().eh_cpy(self.h, a, b)
+
+    def mul_mat(self, a, b):
+        return host().eh_mul_mat(self.h, a, b)
+
+    def rms_norm(self, a, eps):
+        return host().eh_rms_norm(self.h, a, eps)
+
+    def add(self, a, b):
+        return host().eh_bin(self.h, OP_ADD, a, b)
+
+    def mul(self, a, b):
+        return host().eh_bin(self.h, OP_MUL, a, b)
+
+    def bin(self, op, a, b):
+        return host().eh_bin(self.h, op, a, b)
+
+    def unary(self, a, name):
+        return host().eh_unary(self.h, a, UNARY[name])
+
+    def scale(self, a, s):
+        return host().eh_scale(self.h, a, s)
+
+    def concat(self, a, b, dim):
+        return host().eh_concat(self.h, a, b, dim)
+
+    def get_rows(self, a, b):
+        return host().eh_get_rows(self.h, a, b)
+
+    def rope(self, a, pos, n_dims, mode=0, ff=None, n_ctx_orig=0, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0,
+             attn_factor=1.0, beta_fast=32.0, beta_slow=1.0):
+        return host().eh_rope(self.h, a, pos, ff, n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow)
+
+    def soft_max(self, a, mask, scale=1.0, max_bias=0.0):
+        return host().eh_soft_max(self.h, a, mask, scale, max_bias)
+
+    def alloc(self):
+        if host().eh_alloc(self.h) != 0:
+            raise MemoryError("backend buffer allocation failed")
+
+    def compute(self):
+        st = host().eh_compute(self.h)
+        if st != 0:
+            raise RuntimeError(f"graph_compute returned status {st}")
+
+    def supports(self, t):
+        return bool(host().eh_supports(self.h, t))
+
+    def shape(self, t):
+        ne = (C.c_int64 * 4)()
+        nb = (C.c_int64 * 4)()
+        host().eh_shape(t, ne, nb)
+        return list(ne), list(nb)
+
+    def nbytes(self, t):
+        return host().eh_nbytes(t)
+
+    def set(self, t, arr):
+        arr = np.ascontiguousarray(arr)
+        n = self.nbytes(t)
+        assert arr.nbytes == n, f"set: {arr.nbytes} bytes given, tensor spans {n}"
+        host().eh_set(self.h, t, arr.ctypes.data_as(C.c_void_p), 0, n)
+
+    def get(self, t, dtype=np.float32):
+        n = self.nbytes(t)
+        out = np.empty(n // np.dtype(dtype).itemsize, dtype=dtype)
+        host().eh_get(self.h, t, out.ctypes.data_as(C.c_void_p), 0, n)
+        return out

@@ -1,0 +1,37 @@
+// kernels.h -- launchers of the hand-written gfx950 kernels.  Every launcher is asynchronous on
+// `st`, takes the ggml node whose result it produces (sources are read from node->src[]), and
+// assumes mi_supports_op() accepted the node.  Device pointers come from ggml_tensor::data.
+#pragma once
+#include "mi355x_common.h"
+
+// ---- element-wise / small ops (kernels_ops.hip) ----
+void mi_op_rms_norm (hipStream_t st, const ggml_tensor * dst, const ggml_tensor * mul_w /*nullable: fused weight*/, const ggml_tensor * out /*where to write*/);
+void mi_op_bin_bcast(hipStream_t st, const ggml_tensor * dst);          // ADD SUB MUL DIV
+void mi_op_unary    (hipStream_t st, const ggml_tensor * dst);          // SILU RELU GELU ...
+void mi_op_scale    (hipStream_t st, const ggml_tensor * dst);
+void mi_op_cpy      (hipStream_t st, const ggml_tensor * src, const ggml_tensor * dst); // CPY CONT DUP
+void mi_op_concat   (hipStream_t st, const ggml_tensor * dst);
+void mi_op_get_rows (hipStream_t st, const ggml_tensor * dst);
+void mi_op_rope     (hipStream_t st, const ggml_tensor * dst);
+void mi_op_soft_max (hipStream_t st, const ggml_tensor * dst);
+// fused SwiGLU tail: dst = silu(gate) * up   (UNARY(SILU) followed by MUL)
+void mi_op_silu_mul (hipStream_t st, const ggml_tensor * gate, const ggml_tensor * up, const ggml_tensor * dst);
+
+// ---- matrix products (kernels_mmvq.hip / kernels_mmf.hip) ----
+// quantised weight x f32 activations; residual (nullable) is added in the epilogue (fused ADD)
+void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out);
+// f16 / f32 / bf16 src0 x f32 src1 (attention K.q, V.p and unquantised weights)
+void mi_op_mul_mat_f(hipStream_t st, const ggml_tensor * dst);
+bool mi_mul_mat_q_supported_type(int type);
+
+// ---- fused attention for small batches (kernels_attn.hip) ----
+struct mi_attn_args {
+    const void * q;      int64_t q_nb1, q_nb2;          // f32 [d, T, H]   (strides in bytes)
+    const void * k;      int64_t k_nb1, k_nb2;          // f16 [d, n_kv, H_kv]
+    const void * v;      int64_t v_nb1, v_nb2;          // f16 [n_kv, d, H_kv]   (transposed V cache)
+    const void * mask;   int     mask_f16; int64_t mask_nb1;  // [n_kv, >=T]
+    float      * out;    int64_t o_nb1, o_nb2;          // f32, element (dd, h, t) at dd*4 + h*o_nb1 + t*o_nb2
+    int d, T, H, H_kv, n_kv;
+    float scale;
+};
+void mi_op_attn_small(hipStream_t st, const mi_attn_args & a);

@@ -1,0 +1,446 @@
+// kernels_mmvq.hip -- quantised weight x f32 activation products for 1..8 tokens ("mat-vec"),
+// the HBM-bound core of the EAGLE draft step and of tree verification.
+//
+// What it replaces in the reference:  quantize_q8_1 (R/ggml/src/ggml-cuda/quantize.cu:4) +
+// mul_mat_vec_q (R/ggml/src/ggml-cuda/mmvq.cu:55) + vec_dot_*_q8_1 (vecdotq.cuh) -- 32-lane warps,
+// 4-byte loads, Q8_1 activations.  What it computes is the CPU backend's arithmetic instead
+// (that is the parity target): activations are quantised exactly as
+//   quantize_row_q8_K_ref  (R/ggml/src/ggml-quants.c:2479-2512)  for Q4_K / Q5_K / Q6_K weights
+//   quantize_row_q8_0_ref  (R/ggml/src/ggml-quants.c:194-215)    for Q4_0 / Q8_0 weights
+// and the integer dot products are those of ggml_vec_dot_{q4_K,q5_K,q6_K}_q8_K / {q4_0,q8_0}_q8_0
+// (R/ggml/src/ggml-cpu/ggml-cpu-quants.c scalar branches :7020-7078, q5_K/q6_K `#else` tails, :2592-2607),
+// so every int32 partial sum is identical to the CPU's; only the order of the final fp32 adds differs.
+//
+// gfx950 structure (one launch, no scratch):
+//   * prologue: the block quantises the T activation columns straight into LDS (int8 + scales + bsums);
+//     nothing is written to HBM, the separate quantize launch of the reference disappears;
+//   * main loop: a wave owns R=2 weight rows at a time; 8 lanes cover one 256-element super-block with
+//     one 16-byte load each (plus the shared 16-byte header), i.e. a wave instruction streams 8
+//     super-blocks = 1152 B of Q4_K contiguous per row; loads are issued for both rows and two
+//     k-steps before the first use so >=8 x 16 B per lane are in flight;
+//   * v_dot4_i32_i8 on packed nibbles, per-lane fp32 partials, one wave64 butterfly per output;
+//   * epilogue optionally adds a residual row (fused GGML_OP_ADD).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "kernels.h"
+#include <mutex>
+#include <unordered_set>
+
+#define WAVE 64
+typedef int   i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 ld16(const void * p) { i32x4 v; __builtin_memcpy(&v, p, 16); return v; }   // any alignment
+__device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+__device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
+__device__ __forceinline__ int dot16(i32x4 a, i32x4 b) {
+    int s = dot4(a.x, b.x, 0); s = dot4(a.y, b.y, s); s = dot4(a.z, b.z, s); return dot4(a.w, b.w, s);
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = WAVE/2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+
+template <int TYPE> struct wt;
+template <> struct wt<GGML_TYPE_Q4_K> { static constexpr int BS = 144, QK = 256, STEP = 2048; static constexpr bool K = true;  };
+template <> struct wt<GGML_TYPE_Q5_K> { static constexpr int BS = 176, QK = 256, STEP = 2048; static constexpr bool K = true;  };
+template <> struct wt<GGML_TYPE_Q6_K> { static constexpr int BS = 210, QK = 256, STEP = 2048; static constexpr bool K = true;  };
+template <> struct wt<GGML_TYPE_Q8_0> { static constexpr int BS = 34,  QK = 32,  STEP = 1024; static constexpr bool K = false; };
+template <> struct wt<GGML_TYPE_Q4_0> { static constexpr int BS = 18,  QK = 32,  STEP = 2048; static constexpr bool K = false; };
+
+// LDS image of the quantised activations
+struct act_lds {
+    const int8_t * q;   // [T][k]
+    const float  * d;   // [T][k/256] (K types) or [T][k/32] (Q8_0 semantics, value already rounded through fp16)
+    const short  * bs;  // [T][k/16]  (K types only)
+    int k;
+};
+static inline size_t act_lds_bytes(bool ktype, int T, int k) {
+    return ktype ? (size_t) T*k + (size_t) T*(k/256)*4 + (size_t) T*(k/16)*2 : (size_t) T*k + (size_t) T*(k/32)*4;
+}
+
+// ---------------------------------------------------------------- prologue: quantise X[T][k] into LDS
+// Q8_K rule: the scale comes from the FIRST element of largest magnitude, iscale = -127/max,
+// q = min(127, rne(iscale*x)), d = 1/iscale, bsums over groups of 16.
+template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const float * __restrict__ X, int64_t xs, int k, int8_t * q, float * d, short * bs) {
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    const int nsb = k / 256;
+    for (int u = wave; u < T*nsb; u += NW) {
+        const int t = u / nsb, sb = u - t*nsb;
+        const float4 v = *(const float4 *)(X + t*xs + sb*256 + lane*4);
+        const float xv[4] = { v.x, v.y, v.z, v.w };
+        float amax = 0.0f; int first = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float ax = fabsf(xv[j]); if (ax > amax) { amax = ax; first = j; } }
+        float wmax = amax;
+#pragma unroll
+        for (int o = WAVE/2; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, WAVE));
+        int key = (amax == wmax) ? (lane*4 + first) : (1 << 20);      // lowest index holding the maximum
+#pragma unroll
+        for (int o = WAVE/2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o, WAVE));
+        const float cand = (first == 0) ? xv[0] : (first == 1) ? xv[1] : (first == 2) ? xv[2] : xv[3];
+        const float mx = __shfl(cand, (key >> 2) & 63, WAVE);
+        int   packed = 0; int s = 0; float dd = 0.0f;
+        if (wmax != 0.0f) {
+            const float iscale = -127.f / mx;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int qi = __float2int_rn(iscale * xv[j]);
+                qi = min(127, qi);
+                s += qi;
+                packed |= (qi & 0xff) << (8*j);
+            }
+            dd = 1.0f / iscale;
+        }
+        *(int *)(q + (size_t) t*k + sb*256 + lane*4) = packed;
+        s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE);
+        if ((lane & 3) == 0) bs[(size_t) t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
+        if (lane == 0) d[t*nsb + sb] = dd;
+    }
+}
+// Q8_0 rule: d = amax/127, id = 1/d, q = roundf(x*id) (half away from zero), d stored through fp16.
+template <int T, int NW> __device__ __forceinline__ void quant_q80_to_lds(const float * __restrict__ X, int64_t xs, int k, int8_t * q, float * d) {
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    const int nch = k / 256;                       // full 256-element chunks (8 blocks of 32) per wave pass
+    const int nb  = k / 32;
+    for (int u = wave; u < T*nch; u += NW) {
+        const int t = u / nch, ch = u - t*nch;
+        const float4 v = *(const float4 *)(X + t*xs + ch*256 + lane*4);
+        const float xv[4] = { v.x, v.y, v.z, v.w };
+        float amax = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 2, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 4, WAVE));
+        const float dd = amax / 127.f;
+        const float id = dd ? 1.0f/dd : 0.0f;
+        int packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int qi = (int) roundf(xv[j]*id); packed |= (qi & 0xff) << (8*j); }
+        *(int *)(q + (size_t) t*k + ch*256 + lane*4) = packed;
+        if ((lane & 7) == 0) d[t*nb + ch*8 + (lane >> 3)] = __half2float(__float2half_rn(dd));
+    }
+    // ragged tail (k % 256 != 0): blocks of 32 handled by 8-lane groups of wave 0
+    const int tail0 = nch * 256;
+    if (tail0 < k && wave == 0) {
+        for (int t = 0; t < T; ++t) {
+            const int e = tail0 + lane*4;
+            float xv[4] = {0, 0, 0, 0};
+            if (e < k) { const float4 v = *(const float4 *)(X + t*xs + e); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
+            float amax = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
+            amax = fmaxf(amax, __shfl_xor(amax, 1, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 2, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 4, WAVE));
+            const float dd = amax / 127.f;
+            const float id = dd ? 1.0f/dd : 0.0f;
+            int packed = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int qi = (int) roundf(xv[j]*id); packed |= (qi & 0xff) << (8*j); }
+            if (e < k) {
+                *(int *)(q + (size_t) t*k + e) = packed;
+                if ((lane & 7) == 0) d[t*nb + e/32] = __half2float(__float2half_rn(dd));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- per-type weight fragments
+// A "unit" is what one lane loads per k-step: a 16-byte slice of quants plus the scales it needs.
+template <int TYPE> struct wfrag;
+
+// Q4_K: lane (sb, c): c in 0..7 -> quant bytes [16c,16c+16): group g=c/2 (sub-blocks 2g | 2g+1 in low | high nibbles), half h=c%2
+template <> struct wfrag<GGML_TYPE_Q4_K> {
+    i32x4 hdr, qs; bool on;
+    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
+        const int sb = step*8 + (lane >> 3), c = lane & 7;
+        on = sb < k/256;
+        if (on) { const char * b = row + (size_t) sb*144; hdr = ld16(b); qs = ld16(b + 16 + 16*c); }
+        else    { hdr = (i32x4)(0); qs = (i32x4)(0); }
+    }
+    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
+        if (!on) return;
+        const int sb = step*8 + (lane >> 3), c = lane & 7, g = c >> 1, h = c & 1;
+        const float dw = h2f((uint16_t)(hdr.x & 0xffff)), mw = h2f((uint16_t)((uint32_t) hdr.x >> 16));
+        // 6-bit scale/min unpack (get_scale_min_k4, R/ggml/src/ggml-quants.c:631-638) for j = 2g, 2g+1
+        const uint32_t s0 = hdr.y, s1 = hdr.z, s2 = hdr.w;             // scales[0..3], [4..7], [8..11]
+        auto sbyte = [&](int i) -> uint32_t { const uint32_t w = i < 4 ? s0 : (i < 8 ? s1 : s2); return (w >> (8*(i & 3))) & 0xff; };
+        int sc[2], mn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2*g + e;
+            if (j < 4) { sc[e] = sbyte(j) & 63; mn[e] = sbyte(j + 4) & 63; }
+            else       { sc[e] = (sbyte(j + 4) & 0xF) | ((sbyte(j - 4) >> 6) << 4); mn[e] = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
+        }
+        const i32x4 lo = qs & 0x0F0F0F0F, hi = (qs >> 4) & 0x0F0F0F0F;
+        const int eo = sb*256 + 64*g + 16*h;                            // element offset of the low-nibble group
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int8_t * aq = a.q + (size_t) t*a.k + eo;
+            const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 32);
+            const short * bsp = a.bs + (size_t) t*(a.k/16) + sb*16 + 4*g + h;
+            const float dy = a.d[t*(a.k/256) + sb];
+            const int si = sc[0]*dot16(lo, alo) + sc[1]*dot16(hi, ahi);
+            const int mi = mn[0]*(int) bsp[0] + mn[1]*(int) bsp[2];
+            acc[t] += (dw*dy)*(float) si - (mw*dy)*(float) mi;
+        }
+    }
+};
+
+// Q5_K: as Q4_K plus one high bit per element from qh[32]
+template <> struct wfrag<GGML_TYPE_Q5_K> {
+    i32x4 hdr, qh, qs; bool on;
+    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
+        const int sb = step*8 + (lane >> 3), c = lane & 7;
+        on = sb < k/256;
+        if (on) { const char * b = row + (size_t) sb*176; hdr = ld16(b); qh = ld16(b + 16 + 16*(c & 1)); qs = ld16(b + 48 + 16*c); }
+        else    { hdr = (i32x4)(0); qh = (i32x4)(0); qs = (i32x4)(0); }
+    }
+    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
+        if (!on) return;
+        const int sb = step*8 + (lane >> 3), c = lane & 7, g = c >> 1, h = c & 1;
+        const float dw = h2f((uint16_t)(hdr.x & 0xffff)), mw = h2f((uint16_t)((uint32_t) hdr.x >> 16));
+        const uint32_t s0 = hdr.y, s1 = hdr.z, s2 = hdr.w;
+        auto sbyte = [&](int i) -> uint32_t { const uint32_t w = i < 4 ? s0 : (i < 8 ? s1 : s2); return (w >> (8*(i & 3))) & 0xff; };
+        int sc[2], mn[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = 2*g + e;
+            if (j < 4) { sc[e] = sbyte(j) & 63; mn[e] = sbyte(j + 4) & 63; }
+            else       { sc[e] = (sbyte(j + 4) & 0xF) | ((sbyte(j - 4) >> 6) << 4); mn[e] = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
+        }
+        const i32x4 lo = (qs & 0x0F0F0F0F)        | (((qh >> (2*g))     & 0x01010101) << 4);
+        const i32x4 hi = ((qs >> 4) & 0x0F0F0F0F) | (((qh >> (2*g + 1)) & 0x01010101) << 4);
+        const int eo = sb*256 + 64*g + 16*h;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int8_t * aq = a.q + (size_t) t*a.k + eo;
+            const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 32);
+            const short * bsp = a.bs + (size_t) t*(a.k/16) + sb*16 + 4*g + h;
+            const float dy = a.d[t*(a.k/256) + sb];
+            const int si = sc[0]*dot16(lo, alo) + sc[1]*dot16(hi, ahi);
+            const int mi = mn[0]*(int) bsp[0] + mn[1]*(int) bsp[2];
+            acc[t] += (dw*dy)*(float) si - (mw*dy)*(float) mi;
+        }
+    }
+};
+
+// Q6_K: lane (sb, c): half n=c/4, cc=c%4: ql bytes [64n+16cc, +16): low nibbles -> elements 128n+16cc.., high -> +64;
+// the two high bits come from qh[32n + 16(cc%2) ..] at bit offsets 2(cc/2) and 2(cc/2)+4; value - 32.
+template <> struct wfrag<GGML_TYPE_Q6_K> {
+    i32x4 ql, qh; int sc_lo, sc_hi; float dw; bool on;
+    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
+        const int sb = step*8 + (lane >> 3), c = lane & 7, n = c >> 2, cc = c & 3;
+        on = sb < k/256;
+        if (on) {
+            const char * b = row + (size_t) sb*210;
+            ql = ld16(b + 64*n + 16*cc); qh = ld16(b + 128 + 32*n + 16*(cc & 1));
+            const int8_t * s = (const int8_t *)(b + 192 + 8*n + cc);
+            sc_lo = s[0]; sc_hi = s[4];
+            uint16_t dh; __builtin_memcpy(&dh, b + 208, 2); dw = h2f(dh);
+        } else { ql = (i32x4)(0); qh = (i32x4)(0); sc_lo = sc_hi = 0; dw = 0.f; }
+    }
+    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
+        if (!on) return;
+        const int sb = step*8 + (lane >> 3), c = lane & 7, n = c >> 2, cc = c & 3;
+        const int sh = 2*(cc >> 1);
+        const i32x4 lo = (ql & 0x0F0F0F0F)        | (((qh >> sh)       & 0x03030303) << 4);
+        const i32x4 hi = ((ql >> 4) & 0x0F0F0F0F) | (((qh >> (sh + 4)) & 0x03030303) << 4);
+        const int eo = sb*256 + 128*n + 16*cc;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int8_t * aq = a.q + (size_t) t*a.k + eo;
+            const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 64);
+            const short * bsp = a.bs + (size_t) t*(a.k/16) + sb*16 + 8*n + cc;
+            const float dy = a.d[t*(a.k/256) + sb];
+            const int si = sc_lo*(dot16(lo, alo) - 32*(int) bsp[0]) + sc_hi*(dot16(hi, ahi) - 32*(int) bsp[4]);
+            acc[t] += (dw*dy)*(float) si;
+        }
+    }
+};
+
+// Q8_0: two lanes per 32-element block (16 int8 each); the block's int32 sum is completed across the pair
+// before the single fp32 multiply, as in ggml_vec_dot_q8_0_q8_0.
+template <> struct wfrag<GGML_TYPE_Q8_0> {
+    i32x4 qs; float dw; bool on;
+    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
+        const int blk = step*32 + (lane >> 1), h = lane & 1;
+        on = blk < k/32;
+        if (on) { const char * b = row + (size_t) blk*34; uint16_t dh; __builtin_memcpy(&dh, b, 2); dw = h2f(dh); qs = ld16(b + 2 + 16*h); }
+        else    { qs = (i32x4)(0); dw = 0.f; }
+    }
+    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
+        const int blk = step*32 + (lane >> 1), h = lane & 1;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            int s = 0; float dy = 0.f;
+            if (on) { s = dot16(qs, *(const i32x4 *)(a.q + (size_t) t*a.k + blk*32 + 16*h)); dy = a.d[t*(a.k/32) + blk]; }
+            s += __shfl_xor(s, 1, WAVE);
+            if (h == 0) acc[t] += (float) s * (dw*dy);
+        }
+    }
+};
+
+// Q4_0: one lane per block: low nibbles -> elements 0..15, high -> 16..31, value - 8.
+template <> struct wfrag<GGML_TYPE_Q4_0> {
+    i32x4 qs; float dw; bool on;
+    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
+        const int blk = step*64 + lane;
+        on = blk < k/32;
+        if (on) { const char * b = row + (size_t) blk*18; uint16_t dh; __builtin_memcpy(&dh, b, 2); dw = h2f(dh); qs = ld16(b + 2); }
+        else    { qs = (i32x4)(0); dw = 0.f; }
+    }
+    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
+        if (!on) return;
+        const int blk = step*64 + lane;
+        const i32x4 lo = qs & 0x0F0F0F0F, hi = (qs >> 4) & 0x0F0F0F0F;
+        const i32x4 ones = (i32x4)(0x01010101);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int8_t * aq = a.q + (size_t) t*a.k + blk*32;
+            const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 16);
+            const int s = dot16(lo, alo) + dot16(hi, ahi) - 8*(dot16(ones, alo) + dot16(ones, ahi));
+            acc[t] += (float) s * (dw * a.d[t*(a.k/32) + blk]);
+        }
+    }
+};
+
+// ---------------------------------------------------------------- the kernel
+constexpr int MMVQ_R = 2;   // weight rows per wave per pass
+
+template <int TYPE, int T, int NW>
+__global__ void __launch_bounds__(NW*WAVE) k_mmvq(const char * __restrict__ W, int64_t w_row_bytes,
+                                                  const float * __restrict__ X, int64_t x_stride,
+                                                  float * __restrict__ D, int64_t d_stride,
+                                                  const float * __restrict__ RES, int64_t res_stride,
+                                                  int k, int rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using WT = wt<TYPE>;
+    int8_t * lq = (int8_t *) smem;
+    float  * ld = (float *)(smem + (size_t) T*k);
+    short  * lb = (short *)(smem + (size_t) T*k + (size_t) T*(k/256)*4);
+    if (WT::K) quant_q8K_to_lds<T, NW>(X, x_stride, k, lq, ld, lb);
+    else       quant_q80_to_lds<T, NW>(X, x_stride, k, lq, ld);
+    __syncthreads();
+    act_lds a; a.q = lq; a.d = ld; a.bs = lb; a.k = k;
+
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    const int nsteps = (k + WT::STEP - 1) / WT::STEP;
+    for (int row0 = (blockIdx.x*NW + wave)*MMVQ_R; row0 < rows; row0 += gridDim.x*NW*MMVQ_R) {
+        float acc[MMVQ_R][T];
+#pragma unroll
+        for (int r = 0; r < MMVQ_R; ++r)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[r][t] = 0.f;
+        const char * rp[MMVQ_R];
+#pragma unroll
+        for (int r = 0; r < MMVQ_R; ++r) rp[r] = W + (size_t) min(row0 + r, rows - 1) * w_row_bytes;
+
+        for (int s = 0; s < nsteps; s += 2) {
+            wfrag<TYPE> f[2][MMVQ_R];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < MMVQ_R; ++r) f[u][r].load(rp[r], s + u, lane, (s + u < nsteps) ? k : 0);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < MMVQ_R; ++r) f[u][r].template dot<T>(a, s + u, lane, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < MMVQ_R; ++r)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float v = wave_sum_f(acc[r][t]);
+                if (lane == 0 && row0 + r < rows) {
+                    const int64_t row = row0 + r;
+                    D[t*d_stride + row] = RES ? v + RES[t*res_stride + row] : v;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static std::mutex g_attr_mu;
+static std::unordered_set<const void *> g_attr_done;
+static void ensure_lds_attr(const void * fn, size_t bytes) {
+    if (bytes <= 48*1024) return;
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    if (g_attr_done.count(fn)) return;
+    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+    g_attr_done.insert(fn);
+}
+
+template <int TYPE, int T, int NW>
+static void launch_one(hipStream_t st, const char * W, int64_t wrb, const float * X, int64_t xs, float * D, int64_t ds,
+                       const float * RES, int64_t rs, int k, int rows) {
+    const size_t lds = act_lds_bytes(wt<TYPE>::K, T, k);
+    MI_ASSERT(lds <= 160*1024);
+    const int per_block = NW * MMVQ_R;
+    int max_blocks_cu = (int) ((160*1024) / (lds + 1024));
+    if (max_blocks_cu < 1) max_blocks_cu = 1;
+    const int cap_waves = 32 / NW;                                   // 32 waves per CU
+    if (max_blocks_cu > cap_waves) max_blocks_cu = cap_waves;
+    if (max_blocks_cu > 4) max_blocks_cu = 4;
+    int grid = (rows + per_block - 1) / per_block;
+    const int cap = 256 * max_blocks_cu;
+    if (grid > cap) grid = cap;
+    auto fn = k_mmvq<TYPE, T, NW>;
+    ensure_lds_attr((const void *) fn, lds);
+    fn<<<grid, NW*WAVE, lds, st>>>(W, wrb, X, xs, D, ds, RES, rs, k, rows);
+}
+
+template <int TYPE, int T>
+static void launch_T(hipStream_t st, const char * W, int64_t wrb, const float * X, int64_t xs, float * D, int64_t ds,
+                     const float * RES, int64_t rs, int k, int rows) {
+    const size_t lds = act_lds_bytes(wt<TYPE>::K, T, k);
+    if (lds > 36*1024) launch_one<TYPE, T, 8>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows);
+    else               launch_one<TYPE, T, 4 >(st, W, wrb, X, xs, D, ds, RES, rs, k, rows);
+}
+
+template <int TYPE>
+static void launch_type(hipStream_t st, int T, const char * W, int64_t wrb, const float * X, int64_t xs, float * D, int64_t ds,
+                        const float * RES, int64_t rs, int k, int rows) {
+    switch (T) {
+        case 1: launch_T<TYPE, 1>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        case 2: launch_T<TYPE, 2>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        case 3: launch_T<TYPE, 3>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        case 4: launch_T<TYPE, 4>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        case 5: launch_T<TYPE, 5>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        case 6: launch_T<TYPE, 6>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        case 7: launch_T<TYPE, 7>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        case 8: launch_T<TYPE, 8>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        default: MI_ABORT("mmvq: T=%d", T);
+    }
+}
+
+bool mi_mul_mat_q_supported_type(int type) {
+    return type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K || type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q4_0;
+}
+
+// dst[rows, T, b2, b3] = W[k, rows, b2/r2, b3/r3] . X[k, T, b2, b3]   (+ residual)
+void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out) {
+    const ggml_tensor * w = dst->src[0], * x = dst->src[1];
+    const int k = (int) w->ne[0], rows = (int) w->ne[1];
+    const int64_t Ttot = x->ne[1];
+    if (k == 0 || rows == 0 || Ttot == 0) return;
+    MI_ASSERT(x->type == GGML_TYPE_F32 && x->nb[0] == 4 && out->nb[0] == 4);
+    const int64_t r2 = x->ne[2] / w->ne[2], r3 = x->ne[3] / w->ne[3];
+    // tokens per launch: as many as fit one CU's LDS (8 at most)
+    const size_t per_tok = act_lds_bytes(mi_traits(w->type).blck == 256, 1, k);
+    int tmax = (int) ((150*1024) / per_tok);
+    if (tmax > 8) tmax = 8;
+    MI_ASSERT(tmax >= 1);
+    for (int64_t i3 = 0; i3 < x->ne[3]; ++i3) for (int64_t i2 = 0; i2 < x->ne[2]; ++i2) {
+        const char  * W = (const char *) w->data + (i2/r2)*w->nb[2] + (i3/r3)*w->nb[3];
+        for (int64_t t0 = 0; t0 < Ttot; t0 += tmax) {
+            const int T = (int) ((Ttot - t0) < tmax ? (Ttot - t0) : tmax);
+            const float * X = (const float *)((const char *) x->data + t0*x->nb[1] + i2*x->nb[2] + i3*x->nb[3]);
+            float       * D = (float *)((char *) out->data + t0*out->nb[1] + i2*out->nb[2] + i3*out->nb[3]);
+            const float * R = residual ? (const float *)((const char *) residual->data + t0*residual->nb[1] + i2*residual->nb[2] + i3*residual->nb[3]) : nullptr;
+            const int64_t xs = x->nb[1]/4, ds = out->nb[1]/4, rs = residual ? residual->nb[1]/4 : 0;
+            switch (w->type) {
+                case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
+                case GGML_TYPE_Q5_K: launch_type<GGML_TYPE_Q5_K>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
+                case GGML_TYPE_Q6_K: launch_type<GGML_TYPE_Q6_K>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
+                case GGML_TYPE_Q8_0: launch_type<GGML_TYPE_Q8_0>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
+                case GGML_TYPE_Q4_0: launch_type<GGML_TYPE_Q4_0>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
+                default: MI_ABORT("mmvq: unsupported weight type %d", w->type);
+            }
+        }
+    }
+}

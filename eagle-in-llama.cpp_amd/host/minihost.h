@@ -1,0 +1,104 @@
+// minihost.h -- the host side above the C ABI: a small C++ counterpart of the parts of ggml that sit
+// above the backend vtables (tensor/op constructors, graph assembly, buffer allocation, backend
+// loading).  It talks to ANY library that implements the reference's backend ABI (include/ggml_abi.h):
+// our MI355X plugin ("ggml_backend_init") and, in tests and for the CPU baseline, the reference's own
+// CPU backend built under oracle/_ref ("ggml_backend_cpu_reg") -- the very same graphs run on both.
+//
+// Constructors fill ggml_tensor exactly as the reference's do (names, op_params slots, view rules):
+//   ggml_new_tensor / view / reshape / permute / transpose / cont / cpy     R/ggml/src/ggml.c
+//   ggml_mul_mat, ggml_rms_norm, ggml_rope_ext, ggml_soft_max_ext, ...      R/ggml/src/ggml.c
+#pragma once
+#include "ggml_abi.h"
+#include <cstddef>
+#include <cstdint>
+#include <deque>
+#include <string>
+#include <vector>
+
+namespace mh {
+
+struct type_traits { int blck; int size; };
+type_traits traits(int type);
+size_t row_size(int type, int64_t ne0);
+size_t nbytes(const ggml_tensor * t);
+int64_t nelements(const ggml_tensor * t);
+bool   is_contiguous(const ggml_tensor * t);
+
+// A loaded backend: registry -> device -> stream, plus its default buffer type.
+struct Backend {
+    void * dl = nullptr;
+    ggml_backend_reg_t reg = nullptr;
+    ggml_backend_dev_t dev = nullptr;
+    ggml_backend_t     be  = nullptr;
+    ggml_backend_buffer_type_t buft = nullptr;
+    std::string path, entry;
+    bool is_host = false;
+
+    static Backend * load(const char * so_path, const char * entry_symbol, int device_index, std::string * err);
+    ~Backend();
+    const char * name() const;
+    void set_n_threads(int n);                 // via get_proc_address("ggml_backend_set_n_threads") when offered
+    void synchronize();
+    bool supports_op(const ggml_tensor * t) const;
+    ggml_backend_buffer_t alloc_buffer(size_t size, int usage);
+    void free_buffer(ggml_backend_buffer_t b);
+};
+
+// Tensor arena + op list + device memory for one graph (or for a set of persistent tensors).
+struct Ctx {
+    Backend * be;
+    std::deque<ggml_tensor> pool;
+    std::vector<ggml_tensor *> nodes;            // ops in creation order == execution order
+    std::vector<ggml_backend_buffer_t> buffers;  // owned
+    std::vector<ggml_tensor **> node_ptrs_storage;
+    int usage = GGML_BACKEND_BUFFER_USAGE_ANY;
+
+    explicit Ctx(Backend * b) : be(b) {}
+    ~Ctx();
+
+    ggml_tensor * new_tensor(int type, int64_t ne0, int64_t ne1 = 1, int64_t ne2 = 1, int64_t ne3 = 1, const char * name = nullptr);
+    // views (no data of their own)
+    ggml_tensor * view(ggml_tensor * a, int n_dims, const int64_t * ne, const size_t * nb /* nb[1..n_dims-1] */, size_t offset);
+    ggml_tensor * view_1d(ggml_tensor * a, int64_t ne0, size_t offset);
+    ggml_tensor * view_2d(ggml_tensor * a, int64_t ne0, int64_t ne1, size_t nb1, size_t offset);
+    ggml_tensor * view_3d(ggml_tensor * a, int64_t ne0, int64_t ne1, int64_t ne2, size_t nb1, size_t nb2, size_t offset);
+    ggml_tensor * reshape(ggml_tensor * a, int64_t ne0, int64_t ne1 = 1, int64_t ne2 = 1, int64_t ne3 = 1);
+    ggml_tensor * permute(ggml_tensor * a, int ax0, int ax1, int ax2, int ax3);
+    ggml_tensor * transpose(ggml_tensor * a);
+    // ops
+    ggml_tensor * cont(ggml_tensor * a);
+    ggml_tensor * cont_2d(ggml_tensor * a, int64_t ne0, int64_t ne1);
+    ggml_tensor * cpy(ggml_tensor * a, ggml_tensor * b);
+    ggml_tensor * mul_mat(ggml_tensor * a, ggml_tensor * b);
+    ggml_tensor * rms_norm(ggml_tensor * a, float eps);
+    ggml_tensor * add(ggml_tensor * a, ggml_tensor * b);
+    ggml_tensor * mul(ggml_tensor * a, ggml_tensor * b);
+    ggml_tensor * bin(int op, ggml_tensor * a, ggml_tensor * b);
+    ggml_tensor * unary(ggml_tensor * a, int uop);
+    ggml_tensor * scale(ggml_tensor * a, float s);
+    ggml_tensor * concat(ggml_tensor * a, ggml_tensor * b, int dim);
+    ggml_tensor * get_rows(ggml_tensor * a, ggml_tensor * b);
+    ggml_tensor * rope_ext(ggml_tensor * a, ggml_tensor * pos, ggml_tensor * ff, int n_dims, int mode, int n_ctx_orig,
+                           float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow);
+    ggml_tensor * soft_max_ext(ggml_tensor * a, ggml_tensor * mask, float scale, float max_bias);
+
+    void set_name(ggml_tensor * t, const char * name);
+    // give every tensor that owns data and has none yet a place in one new backend buffer
+    bool alloc();
+    // drop all ops/tensors but keep the buffers for re-use by the next alloc() (per-step graphs)
+    void reset_graph();
+    void set(ggml_tensor * t, const void * data, size_t offset, size_t size);
+    void get(const ggml_tensor * t, void * data, size_t offset, size_t size);
+    enum ggml_status compute();                  // graph_compute over `nodes` + synchronize
+    enum ggml_status compute_async();
+
+  private:
+    ggml_tensor * op_result(int op, int type, const int64_t * ne, ggml_tensor * a, ggml_tensor * b = nullptr, ggml_tensor * c = nullptr);
+    ggml_tensor * view_impl(ggml_tensor * a, int op);
+    size_t reuse_cap = 0;                        // capacity of buffers.back() when it is the reusable compute buffer
+    bool   reuse = false;
+    std::vector<ggml_tensor *> node_array;
+    ggml_cgraph graph{};
+};
+
+} // namespace mh

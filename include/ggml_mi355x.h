@@ -1,0 +1,53 @@
+/*
+ * ggml_mi355x.h -- exported C ABI of libggml-mi355x.so, the MI355X (gfx950) backend plugin that makes
+ * llama_decode() / llama_decode_draft() / the speculative EAGLE drivers of mkjsym/EAGLE-in-llama.cpp run
+ * on AMD Instinct MI355X without touching the reference's sources.
+ *
+ * Every entry point below is one the reference's own loader binds; nothing else is needed to drop the
+ * library in (R = /root/reference/llama.cpp):
+ *
+ *   ggml_backend_init     required by  R/ggml/src/ggml-backend-reg.cpp:237  (dlsym "ggml_backend_init"),
+ *                         contract in  R/ggml/src/ggml-backend-impl.h:215,220-228 (GGML_BACKEND_DL_IMPL).
+ *                         Returns the registry object; reg->api_version must be 1 (reg.cpp:246).
+ *   ggml_backend_score    optional,    R/ggml/src/ggml-backend-reg.cpp:229-235; 0 => "not usable here".
+ *
+ * Loading:  GGML_BACKEND_PATH=/path/libggml-mi355x.so <any reference binary>      (reg.cpp:578-581)
+ *      or:  ggml_backend_load("/path/libggml-mi355x.so")                          (reg.cpp:393)
+ *      or:  copy next to the executable as libggml-hip-mi355x.so                  (reg.cpp:568 name probe)
+ *
+ * Everything else crosses the boundary through the five vtables reachable from the returned registry
+ * (layout stated in ggml_abi.h): get_device -> {init_backend, get_buffer_type, supports_op, ...} ->
+ * ggml_backend_i::graph_compute, which is the hot path (R/ggml/src/ggml-backend.cpp:1397).
+ *
+ * Named extension points the reference looks up with reg->iface.get_proc_address():
+ *   "ggml_backend_split_buffer_type"  (R/src/llama-model.cpp:310-322, -sm row)  -> ggml_backend_mi355x_split_buffer_type
+ *   "ggml_backend_get_features"       (R/src/llama.cpp:12044)                    -> feature list
+ */
+#ifndef GGML_MI355X_H
+#define GGML_MI355X_H
+
+#include "ggml_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGML_MI355X_API __attribute__((visibility("default")))
+
+/* dlopen protocol of the reference (see above) */
+GGML_MI355X_API ggml_backend_reg_t ggml_backend_init(void);
+GGML_MI355X_API int                ggml_backend_score(void);
+
+/* static-link style accessors, same role as ggml_backend_cuda_reg() / ggml_backend_cuda_get_device_count()
+ * (R/ggml/include/ggml-cuda.h:24-47) for hosts that link the library instead of dlopen-ing it */
+GGML_MI355X_API ggml_backend_reg_t ggml_backend_mi355x_reg(void);
+GGML_MI355X_API int                ggml_backend_mi355x_device_count(void);
+
+/* row-split (tensor-parallel) weight buffers, signature of ggml_backend_split_buffer_type_t
+ * (R/ggml/include/ggml-backend.h:188); tensor_split has one entry per device, NULL => even split */
+GGML_MI355X_API ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device, const float * tensor_split);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
