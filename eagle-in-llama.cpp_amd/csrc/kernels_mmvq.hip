@@ -294,7 +294,7 @@ template <> struct wfrag<GGML_TYPE_Q4_0> {
             const int8_t * aq = a.q + (size_t) t*a.k + blk*32;
             const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 16);
             const int s = dot16(lo, alo) + dot16(hi, ahi) - 8*(dot16(ones, alo) + dot16(ones, ahi));
-            acc[t] += (float) s * (dw * a.d[t*(a.k/32) + blk]);
+            acc[t] += ((float) s * dw) * a.d[t*(a.k/32) + blk];      // (sumi*dx)*dy, ggml-cpu-quants.c:2606
         }
     }
 };
