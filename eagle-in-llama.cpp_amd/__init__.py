@@ -228,3 +228,150 @@ class Graph:
         out = np.empty(n // np.dtype(dtype).itemsize, dtype=dtype)
         host().eh_get(self.h, t, out.ctypes.data_as(C.c_void_p), 0, n)
         return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# models + speculative driver (host/model.cpp, host/driver.cpp)
+FTYPE = {"q4_0": 0, "q4_k_m": 1, "q8_0": 2}
+STAT_NAMES = ["n_predict", "n_drafted", "n_accept", "n_iters", "t_prompt_us", "t_decode_us", "t_draft_us", "t_verify_us",
+              "n_draft_calls", "n_target_calls"]
+
+CONFIGS = {
+    # name: (n_embd, n_head, n_head_kv, head_dim, n_ff, n_layer, n_vocab)
+    "vicuna-7b": (4096, 32, 32, 128, 11008, 32, 32000),
+    "llama-2-13b": (5120, 40, 40, 128, 13824, 40, 32000),
+    "llama-2-70b": (8192, 64, 8, 128, 28672, 80, 32000),
+    "tiny": (256, 4, 4, 64, 768, 2, 512),            # CPU-checkable in seconds (every dim a multiple of 256)
+    "tiny-gqa": (512, 8, 2, 64, 1024, 3, 768),
+}
+
+
+def _model_sigs():
+    h = host()
+    if getattr(h, "_model_sigs_done", False):
+        return h
+    vp, i64, i32, f32, f64p = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.POINTER(C.c_double)
+    i32p = C.POINTER(C.c_int32)
+    sig = {
+        "eh_model_create": (vp, [vp, i32p, f32, f32, C.c_uint64, f32, i32, vp]),
+        "eh_model_free": (None, [vp]), "eh_model_weight_bytes": (i64, [vp]), "eh_model_n_nodes": (i32, [vp]),
+        "eh_model_decode": (i32, [vp, i32, i32p, i32p, i32p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), i32]),
+        "eh_model_n_outputs": (i32, [vp]), "eh_model_logits": (C.POINTER(C.c_float), [vp]), "eh_model_hidden": (C.POINTER(C.c_float), [vp]),
+        "eh_model_kv_clear": (None, [vp]), "eh_model_kv_seq_rm": (None, [vp, i32, i32, i32]),
+        "eh_model_kv_seq_cp": (None, [vp, i32, i32, i32, i32]), "eh_model_kv_seq_keep": (None, [vp, i32]),
+        "eh_model_timers": (None, [vp, f64p]), "eh_model_timers_reset": (None, [vp]),
+        "eh_spec_run": (i32, [vp, vp, i32p, i32, i32, i32, f32, i32p, f64p]),
+        "eh_spec_begin": (vp, [vp, vp, i32p, i32]), "eh_spec_rounds": (i32, [vp, i32, i32, f32, i32p, i32, f64p]), "eh_spec_end": (None, [vp]),
+        "eh_plain_run": (i32, [vp, i32p, i32, i32, i32p, f64p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(h, name)
+        fn.restype, fn.argtypes = res, args
+    h._model_sigs_done = True
+    return h
+
+
+class Model:
+    """Synthetic llama (target) or EAGLE head (draft) with the reference's tensor shapes and quantisation mix."""
+
+    def __init__(self, backend, config="vicuna-7b", ftype="q4_k_m", n_ctx=2048, eagle_of=None, seed=42, accept_p=0.8,
+                 predictable=True, rms_eps=1e-6, rope_base=10000.0):
+        h = _model_sigs()
+        dims = list(CONFIGS[config]) if isinstance(config, str) else list(config)
+        if eagle_of is not None:
+            dims[5] = 1
+        ci = (C.c_int32 * 10)(*dims, n_ctx, FTYPE[ftype], 1 if eagle_of is not None else 0)
+        self.be, self.dims, self.n_ctx, self.ftype = backend, dims, n_ctx, ftype
+        self.n_embd, self.n_vocab = dims[0], dims[6]
+        self.target = eagle_of
+        self.h = h.eh_model_create(backend.h, ci, rms_eps, rope_base, seed, accept_p, 1 if predictable else 0, eagle_of.h if eagle_of else None)
+        if not self.h:
+            raise MemoryError("model allocation failed")
+
+    def close(self):
+        if self.h:
+            _model_sigs().eh_model_free(self.h)
+            self.h = None
+
+    @property
+    def weight_bytes(self):
+        return _model_sigs().eh_model_weight_bytes(self.h)
+
+    @property
+    def n_nodes(self):
+        return _model_sigs().eh_model_n_nodes(self.h)
+
+    def decode(self, tokens, pos, seq=None, logits=None, hidd=None, want_hidden=True):
+        h = _model_sigs()
+        n = len(tokens)
+        tk = (C.c_int32 * n)(*tokens); ps = (C.c_int32 * n)(*pos)
+        sq = (C.c_int32 * n)(*seq) if seq is not None else None
+        lg = (C.c_uint8 * n)(*[1 if x else 0 for x in logits]) if logits is not None else None
+        hp = None
+        if hidd is not None:
+            hidd = np.ascontiguousarray(hidd, np.float32); hp = hidd.ctypes.data_as(C.POINTER(C.c_float))
+        rc = h.eh_model_decode(self.h, n, tk, ps, sq, lg, hp, 1 if want_hidden else 0)
+        if rc != 0:
+            raise RuntimeError(f"decode returned {rc}")
+        no = h.eh_model_n_outputs(self.h)
+        lgs = np.ctypeslib.as_array(h.eh_model_logits(self.h), (no, self.n_vocab)).copy()
+        hid = np.ctypeslib.as_array(h.eh_model_hidden(self.h), (no, self.n_embd)).copy() if want_hidden else None
+        return lgs, hid
+
+    def kv_clear(self):
+        _model_sigs().eh_model_kv_clear(self.h)
+
+    def kv_seq_rm(self, seq, p0, p1):
+        _model_sigs().eh_model_kv_seq_rm(self.h, seq, p0, p1)
+
+    def timers(self, reset=False):
+        t = (C.c_double * 5)()
+        _model_sigs().eh_model_timers(self.h, t)
+        if reset:
+            _model_sigs().eh_model_timers_reset(self.h)
+        return dict(build_us=t[0], upload_us=t[1], compute_us=t[2], download_us=t[3], n_decode=int(t[4]))
+
+
+def spec_generate(target, draft, prompt, n_predict, n_draft=5, p_min=0.0):
+    h = _model_sigs()
+    n = len(prompt)
+    pr = (C.c_int32 * n)(*prompt); out = (C.c_int32 * (n_predict + n_draft + 8))(); st = (C.c_double * 16)()
+    k = h.eh_spec_run(target.h, draft.h, pr, n, n_predict, n_draft, p_min, out, st)
+    if k < 0:
+        raise RuntimeError(f"eh_spec_run returned {k}")
+    return list(out[:k]), {nm: st[i] for i, nm in enumerate(STAT_NAMES)}
+
+
+def plain_generate(target, prompt, n_predict):
+    h = _model_sigs()
+    n = len(prompt)
+    pr = (C.c_int32 * n)(*prompt); out = (C.c_int32 * (n_predict + 8))(); st = (C.c_double * 16)()
+    k = h.eh_plain_run(target.h, pr, n, n_predict, out, st)
+    if k < 0:
+        raise RuntimeError(f"eh_plain_run returned {k}")
+    return list(out[:k]), {nm: st[i] for i, nm in enumerate(STAT_NAMES)}
+
+
+class SpecSession:
+    """Prompt once, then run timed batches of speculative rounds (bench.py)."""
+
+    def __init__(self, target, draft, prompt):
+        h = _model_sigs()
+        pr = (C.c_int32 * len(prompt))(*prompt)
+        self.h = h.eh_spec_begin(target.h, draft.h, pr, len(prompt))
+        if not self.h:
+            raise RuntimeError("prompt processing failed")
+
+    def rounds(self, n, n_draft=5, p_min=0.0):
+        h = _model_sigs()
+        cap = n * (n_draft + 2)
+        out = (C.c_int32 * cap)(); st = (C.c_double * 16)()
+        k = h.eh_spec_rounds(self.h, n, n_draft, p_min, out, cap, st)
+        if k < 0:
+            raise RuntimeError(f"eh_spec_rounds returned {k}")
+        return list(out[:k]), {nm: st[i] for i, nm in enumerate(STAT_NAMES)}
+
+    def close(self):
+        if self.h:
+            _model_sigs().eh_spec_end(self.h)
+            self.h = None

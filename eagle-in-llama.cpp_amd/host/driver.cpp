@@ -1,0 +1,219 @@
+// driver.cpp -- the speculative-decoding loops above llama_decode(), mirroring
+//   chain driver   R/examples/speculative-simple/speculative-eagle.cpp:150-362  (decode_init / decode_initial /
+//                  common_speculative_gen_draft R/common/speculative.cpp:137-299 / llama_decode / accept)
+//   accept rule    common_sampler_sample_and_accept_n, R/common/sampling.cpp:423-451 (greedy: accept while the target's
+//                  argmax equals the drafted token, then one bonus token)
+//   KV fix-up      llama_kv_cache_seq_rm(ctx, 0, n_past, -1)  (speculative-eagle.cpp:355)
+// and the plain (non-speculative) loop used as the 1x reference for the ">= 2x" target.
+//
+// Differences from the reference, all deliberate (bugs not to reproduce):
+//   * the draft is fed the TARGET's feature of every accepted token at the start of a round (EAGLE's re-ingest),
+//     not its own stale feature (A.5) and never uninitialised memory (A.1);
+//   * prompt features come from the target's prompt pass.
+#include "model.h"
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#define EH_API extern "C" __attribute__((visibility("default")))
+using namespace eh;
+
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int argmax(const float * v, int n) { int b = 0; float m = v[0]; for (int i = 1; i < n; ++i) if (v[i] > m) { m = v[i]; b = i; } return b; }
+static float top_prob(const float * v, int n, int best) { double s = 0; const float m = v[best]; for (int i = 0; i < n; ++i) s += std::exp((double)(v[i] - m)); return (float)(1.0 / s); }
+
+enum { ST_N_PREDICT, ST_N_DRAFTED, ST_N_ACCEPT, ST_N_ITERS, ST_T_PROMPT_US, ST_T_DECODE_US, ST_T_DRAFT_US, ST_T_VERIFY_US, ST_N_DRAFT_CALLS, ST_N_TARGET_CALLS, ST_COUNT };
+
+struct SpecState {
+    Model * tgt; Model * dft;
+    int n_past = 0;                 // tokens whose K/V are valid in the target cache
+    int32_t id_last = -1;           // sampled, not yet decoded by the target
+    std::vector<int32_t> re_tok;    // accepted tokens of the previous round the draft has to (re-)ingest ...
+    std::vector<float>   re_feat;   // ... with the target's features [re_tok.size()][n_embd]
+    int re_pos0 = 0;                // position of re_tok[0]
+    Batch bt, bd;
+    std::vector<int32_t> drafts;
+};
+
+// prompt: target over all tokens (features for the draft), draft over tokens 1..n-1
+static int spec_prompt(SpecState & s, const int32_t * prompt, int n) {
+    const int E = s.tgt->cfg.n_embd;
+    s.tgt->kv.clear(); if (s.dft) s.dft->kv.clear();
+    Batch & b = s.bt; b.clear();
+    for (int i = 0; i < n; ++i) b.add(prompt[i], i, 0, true);
+    int rc = s.tgt->decode(b, true);
+    if (rc) return rc;
+    s.n_past = n;
+    s.id_last = argmax(s.tgt->logits_ith(n - 1), s.tgt->cfg.n_vocab);
+    if (s.dft) {
+        if (n > 1) {
+            Batch & d = s.bd; d.clear();
+            for (int i = 1; i < n; ++i) d.add(prompt[i], i, 0, i == n - 1);
+            d.hidd.assign(s.tgt->hidden.begin(), s.tgt->hidden.begin() + (size_t)(n - 1) * E);     // F_0 .. F_{n-2}
+            rc = s.dft->decode(d, false);
+            if (rc) return rc;
+        }
+        s.re_tok.assign(1, s.id_last);
+        s.re_feat.assign(s.tgt->hidden_ith(n - 1), s.tgt->hidden_ith(n - 1) + E);
+        s.re_pos0 = n;
+    }
+    return 0;
+}
+
+// one speculative round; returns number of new tokens appended to out (>= 1) or < 0 on error
+static int spec_round(SpecState & s, int n_draft, float p_min, int32_t * out, double * st) {
+    Model & T = *s.tgt, & D = *s.dft;
+    const int E = T.cfg.n_embd, V = T.cfg.n_vocab;
+    const double t0 = now_us();
+    // ---- draft: re-ingest accepted tokens with true features, then autoregress on the draft's own features
+    s.drafts.clear();
+    D.kv.seq_rm(0, s.re_pos0, -1);
+    Batch & d = s.bd; d.clear();
+    const int nre = (int) s.re_tok.size();
+    for (int i = 0; i < nre; ++i) d.add(s.re_tok[i], s.re_pos0 + i, 0, i == nre - 1);
+    d.hidd = s.re_feat;
+    for (int j = 0; j < n_draft; ++j) {
+        int rc = D.decode(d, true);
+        st[ST_N_DRAFT_CALLS] += 1;
+        if (rc) return -10 - rc;
+        const int last = d.n_tokens() - 1;
+        const float * lg = D.logits_ith(last);
+        const int id = argmax(lg, V);
+        if (p_min > 0.0f && top_prob(lg, V, id) < p_min) break;
+        s.drafts.push_back(id);
+        st[ST_N_DRAFTED] += 1;
+        if (j + 1 == n_draft) break;
+        const float * g = D.hidden_ith(last);
+        const int pos = d.pos[last] + 1;
+        std::vector<float> feat(g, g + E);
+        d.clear(); d.add(id, pos, 0, true); d.hidd = std::move(feat);
+    }
+    const double t1 = now_us();
+    // ---- verify: [id_last, drafts...] in one target batch, logits for every token
+    Batch & b = s.bt; b.clear();
+    b.add(s.id_last, s.n_past, 0, true);
+    for (size_t i = 0; i < s.drafts.size(); ++i) b.add(s.drafts[i], s.n_past + 1 + (int) i, 0, true);
+    int rc = T.decode(b, true);
+    st[ST_N_TARGET_CALLS] += 1;
+    if (rc) return -20 - rc;
+    // ---- accept (greedy)
+    int m = 0, n_out = 0;
+    for (;;) {
+        const int tok = argmax(T.logits_ith(m), V);
+        out[n_out++] = tok;
+        if (m < (int) s.drafts.size() && tok == s.drafts[m]) { m++; continue; }
+        break;
+    }
+    st[ST_N_ACCEPT] += m; st[ST_N_PREDICT] += n_out; st[ST_N_ITERS] += 1;
+    // ---- bookkeeping: target keeps id_last + m drafts; next round re-ingests [d1..dm, bonus] with F rows 0..m
+    s.re_tok.assign(out, out + n_out);
+    s.re_feat.resize((size_t) n_out * E);
+    for (int i = 0; i < n_out; ++i) memcpy(s.re_feat.data() + (size_t) i * E, T.hidden_ith(i), (size_t) E * 4);
+    s.re_pos0 = s.n_past + 1;
+    s.n_past += m + 1;
+    T.kv.seq_rm(0, s.n_past, -1);
+    s.id_last = out[n_out - 1];
+    const double t2 = now_us();
+    st[ST_T_DRAFT_US] += t1 - t0; st[ST_T_VERIFY_US] += t2 - t1;
+    return n_out;
+}
+
+EH_API void * eh_model_create(void * backend, const int * ci, float rms_eps, float rope_base, uint64_t seed, float accept_p, int predictable, void * target) {
+    ModelConfig c;
+    c.n_embd = ci[0]; c.n_head = ci[1]; c.n_head_kv = ci[2]; c.head_dim = ci[3]; c.n_ff = ci[4]; c.n_layer = ci[5]; c.n_vocab = ci[6];
+    c.n_ctx = ci[7]; c.ftype = ci[8]; c.eagle = ci[9] != 0; c.rms_eps = rms_eps; c.rope_base = rope_base;
+    SynthOptions o; o.seed = seed; o.accept_p = accept_p; o.predictable = predictable != 0;
+    return Model::create_synthetic((mh::Backend *) backend, c, o, (const Model *) target);
+}
+EH_API void eh_model_free(void * m) { delete (Model *) m; }
+EH_API int64_t eh_model_weight_bytes(void * m) { return (int64_t) ((Model *) m)->weight_bytes; }
+EH_API int eh_model_n_nodes(void * m) { return ((Model *) m)->last_n_nodes; }
+EH_API int eh_model_decode(void * mp, int n, const int32_t * tok, const int32_t * pos, const int32_t * seq, const uint8_t * lg, const float * hidd, int want_hidden) {
+    Model * m = (Model *) mp; Batch b;
+    for (int i = 0; i < n; ++i) b.add(tok[i], pos[i], seq ? seq[i] : 0, lg ? lg[i] != 0 : true);
+    if (hidd) b.hidd.assign(hidd, hidd + (size_t) n * m->cfg.n_embd);
+    return m->decode(b, want_hidden != 0);
+}
+EH_API int eh_model_n_outputs(void * m) { return ((Model *) m)->n_outputs; }
+EH_API const float * eh_model_logits(void * m) { return ((Model *) m)->logits.data(); }
+EH_API const float * eh_model_hidden(void * m) { return ((Model *) m)->hidden.data(); }
+EH_API void eh_model_kv_clear(void * m) { ((Model *) m)->kv.clear(); }
+EH_API void eh_model_kv_seq_rm(void * m, int seq, int p0, int p1) { ((Model *) m)->kv.seq_rm(seq, p0, p1); }
+EH_API void eh_model_kv_seq_cp(void * m, int a, int b, int p0, int p1) { ((Model *) m)->kv.seq_cp(a, b, p0, p1); }
+EH_API void eh_model_kv_seq_keep(void * m, int seq) { ((Model *) m)->kv.seq_keep(seq); }
+EH_API void eh_model_timers(void * mp, double * t) { Model * m = (Model *) mp; t[0] = m->t_build_us; t[1] = m->t_upload_us; t[2] = m->t_compute_us; t[3] = m->t_download_us; t[4] = (double) m->n_decode; }
+EH_API void eh_model_timers_reset(void * mp) { Model * m = (Model *) mp; m->t_build_us = m->t_upload_us = m->t_compute_us = m->t_download_us = 0; m->n_decode = 0; }
+
+// Speculative generation.  stats: ST_* doubles.  Returns tokens generated, < 0 on error.
+EH_API int eh_spec_run(void * tgt, void * dft, const int32_t * prompt, int n_prompt, int n_predict, int n_draft, float p_min,
+                       int32_t * out_tokens, double * stats) {
+    SpecState s; s.tgt = (Model *) tgt; s.dft = (Model *) dft;
+    for (int i = 0; i < ST_COUNT; ++i) stats[i] = 0;
+    const double t0 = now_us();
+    int rc = spec_prompt(s, prompt, n_prompt);
+    if (rc) return -1000 - rc;
+    const double t1 = now_us();
+    stats[ST_T_PROMPT_US] = t1 - t0;
+    int n = 0;
+    out_tokens[n++] = s.id_last; stats[ST_N_PREDICT] = 1;
+    std::vector<int32_t> tmp((size_t) n_draft + 2);
+    while (n < n_predict) {
+        if (s.n_past + n_draft + 2 >= s.tgt->cfg.n_ctx) break;
+        const int k = spec_round(s, n_draft, p_min, tmp.data(), stats);
+        if (k < 0) return k;
+        for (int i = 0; i < k && n < n_predict; ++i) out_tokens[n++] = tmp[i];
+    }
+    stats[ST_T_DECODE_US] = now_us() - t1;
+    return n;
+}
+// one call = exactly `rounds` speculative rounds continuing from a primed state (bench.py times this)
+struct SpecSession { SpecState s; std::vector<int32_t> tmp; };
+EH_API void * eh_spec_begin(void * tgt, void * dft, const int32_t * prompt, int n_prompt) {
+    SpecSession * ss = new SpecSession; ss->s.tgt = (Model *) tgt; ss->s.dft = (Model *) dft;
+    if (spec_prompt(ss->s, prompt, n_prompt)) { delete ss; return nullptr; }
+    return ss;
+}
+EH_API int eh_spec_rounds(void * sp, int rounds, int n_draft, float p_min, int32_t * out_tokens, int out_cap, double * stats) {
+    SpecSession * ss = (SpecSession *) sp; ss->tmp.resize((size_t) n_draft + 2);
+    for (int i = 0; i < ST_COUNT; ++i) stats[i] = 0;
+    int n = 0;
+    const double t0 = now_us();
+    for (int r = 0; r < rounds; ++r) {
+        if (ss->s.n_past + n_draft + 2 >= ss->s.tgt->cfg.n_ctx) return -5;
+        const int k = spec_round(ss->s, n_draft, p_min, ss->tmp.data(), stats);
+        if (k < 0) return k;
+        for (int i = 0; i < k; ++i) if (n < out_cap) out_tokens[n++] = ss->tmp[i];
+    }
+    stats[ST_T_DECODE_US] = now_us() - t0;
+    return n;
+}
+EH_API void eh_spec_end(void * sp) { delete (SpecSession *) sp; }
+
+// Plain autoregressive decoding (what the speculative path must beat by >= 2x)
+EH_API int eh_plain_run(void * tgt, const int32_t * prompt, int n_prompt, int n_predict, int32_t * out_tokens, double * stats) {
+    Model * T = (Model *) tgt;
+    for (int i = 0; i < ST_COUNT; ++i) stats[i] = 0;
+    const double t0 = now_us();
+    T->kv.clear();
+    Batch b;
+    for (int i = 0; i < n_prompt; ++i) b.add(prompt[i], i, 0, i == n_prompt - 1);
+    int rc = T->decode(b, false);
+    if (rc) return -1000 - rc;
+    const double t1 = now_us();
+    stats[ST_T_PROMPT_US] = t1 - t0;
+    int n = 0, n_past = n_prompt;
+    int id = argmax(T->logits_ith(n_prompt - 1), T->cfg.n_vocab);
+    out_tokens[n++] = id;
+    while (n < n_predict && n_past + 1 < T->cfg.n_ctx) {
+        b.clear(); b.add(id, n_past, 0, true);
+        rc = T->decode(b, false);
+        stats[ST_N_TARGET_CALLS] += 1;
+        if (rc) return -20 - rc;
+        n_past++;
+        id = argmax(T->logits_ith(0), T->cfg.n_vocab);
+        out_tokens[n++] = id;
+    }
+    stats[ST_N_PREDICT] = n; stats[ST_T_DECODE_US] = now_us() - t1;
+    return n;
+}

@@ -1,0 +1,399 @@
+// model.cpp -- see model.h.  Synthetic weights + llama / eagle graph construction + decode.
+#include "model.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+namespace eh {
+
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ------------------------------------------------------------------ fp16 helpers (IEEE, round to nearest even)
+static inline uint16_t f2h(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u, ax = x & 0x7fffffffu;
+    if (ax > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);
+    const int e = (int)(ax >> 23) - 127;
+    if (e > 15) return (uint16_t)(sign | 0x7c00u);
+    const uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    int shift = 13; uint32_t base = 0;
+    if (e < -14) { shift = 13 + (-14 - e); if (shift > 25) return (uint16_t) sign; } else base = (uint32_t)(e + 14) << 10;
+    uint32_t q = m >> shift; const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) q++;
+    return (uint16_t)(sign | (base + q));
+}
+static inline float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) { if (!man) bits = sign; else { int e = -1; uint32_t m = man; do { e++; m <<= 1; } while (!(m & 0x400u)); bits = sign | ((uint32_t)(112 - e) << 23) | ((m & 0x3ffu) << 13); } }
+    else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 112) << 23) | (man << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+
+size_t row_bytes(int type, int64_t k) { return mh::row_size(type, k); }
+
+static bool use_more_bits(int il, int n) { return il < n/8 || il >= 7*n/8 || (il - n/8) % 3 == 2; }   // R/src/llama-quant.cpp:129-131
+int weight_type_for(const ModelConfig & c, const char * which, int il) {
+    const std::string w = which;
+    if (c.ftype == FTYPE_Q8_0) return GGML_TYPE_Q8_0;
+    if (w == "output") return GGML_TYPE_Q6_K;                       // llama-quant.cpp:151-166
+    if (c.ftype == FTYPE_Q4_0) return GGML_TYPE_Q4_0;
+    if ((w == "wv" || w == "down") && use_more_bits(il, c.n_layer)) return GGML_TYPE_Q6_K;   // :235-236, :291-296
+    return GGML_TYPE_Q4_K;
+}
+
+// ------------------------------------------------------------------ KV cells
+bool KVCache::find_slot(const Batch & b) {
+    const uint32_t n_tokens = (uint32_t) b.n_tokens();
+    if (n_tokens > size) return false;
+    uint32_t n_tested = 0;
+    while (true) {
+        if (head + n_tokens > size) { n_tested += size - head; head = 0; continue; }
+        bool found = true;
+        for (uint32_t i = 0; i < n_tokens; i++) if (cells[head + i].pos >= 0) { found = false; head += i + 1; n_tested += i + 1; break; }
+        if (found) break;
+        if (n_tested >= size) return false;
+    }
+    for (uint32_t k = 0; k < n_tokens; ++k) { cells[head + k].pos = b.pos[k]; cells[head + k].seqs |= b.seq_mask[k]; }
+    used += n_tokens;
+    return true;
+}
+uint32_t KVCache::cell_max() const { for (uint32_t i = size; i > 0; --i) if (cells[i-1].pos >= 0 && cells[i-1].seqs) return i; return 0; }
+void KVCache::seq_rm(int seq, int32_t p0, int32_t p1) {
+    uint32_t new_head = size;
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = INT32_MAX;
+    for (uint32_t i = 0; i < size; ++i) if (cells[i].pos >= p0 && cells[i].pos < p1) {
+        if (seq < 0) cells[i].seqs = 0;
+        else if (cells[i].seqs & (1ull << seq)) cells[i].seqs &= ~(1ull << seq);
+        else continue;
+        if (!cells[i].seqs) { if (cells[i].pos >= 0) used--; cells[i].pos = -1; if (new_head == size) new_head = i; }
+    }
+    if (new_head != size && new_head < head) head = new_head;
+}
+void KVCache::seq_cp(int src, int dst, int32_t p0, int32_t p1) {
+    if (p0 < 0) p0 = 0;
+    if (p1 < 0) p1 = INT32_MAX;
+    head = 0;
+    for (uint32_t i = 0; i < size; ++i) if ((cells[i].seqs & (1ull << src)) && cells[i].pos >= p0 && cells[i].pos < p1) cells[i].seqs |= 1ull << dst;
+}
+void KVCache::seq_keep(int seq) {
+    uint32_t new_head = size;
+    for (uint32_t i = 0; i < size; ++i) {
+        if (!(cells[i].seqs & (1ull << seq))) { if (cells[i].pos >= 0) used--; cells[i].pos = -1; cells[i].seqs = 0; if (new_head == size) new_head = i; }
+        else cells[i].seqs = 1ull << seq;
+    }
+    if (new_head != size && new_head < head) head = new_head;
+}
+
+// ------------------------------------------------------------------ synthetic weights
+struct Rng { uint64_t s; explicit Rng(uint64_t seed) : s(seed) {} uint64_t next() { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+             double uni() { return (next() >> 11) * (1.0 / 9007199254740992.0); } };
+
+// random but valid blocks; `scale` ~ std of the dequantised weights
+static void fill_blocks(int type, uint8_t * dst, int64_t rows, int64_t k, uint64_t seed, float scale) {
+    const auto tr = mh::traits(type);
+    const int64_t nb = rows * (k / tr.blck);
+    #pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < nb; ++b) {
+        Rng r(seed * 0x100000001B3ull + (uint64_t) b);
+        uint8_t * p = dst + b * tr.size;
+        for (int i = 0; i < tr.size; i += 8) { uint64_t v = r.next(); memcpy(p + i, &v, std::min(8, tr.size - i)); }
+        const float u = 0.5f + (float) r.uni();
+        uint16_t h;
+        switch (type) {
+            case GGML_TYPE_Q4_0: h = f2h(scale / 4.6f * u); memcpy(p, &h, 2); break;                          // q-8 uniform: std 4.6
+            case GGML_TYPE_Q8_0: h = f2h(scale / 74.f * u); memcpy(p, &h, 2); break;                          // int8 uniform: std 74
+            case GGML_TYPE_Q4_K: h = f2h(scale / (18.f*4.6f) * u); memcpy(p, &h, 2); h = f2h(scale / (18.f*2.f) * (0.5f + (float) r.uni())); memcpy(p + 2, &h, 2); break;
+            case GGML_TYPE_Q5_K: h = f2h(scale / (18.f*9.2f) * u); memcpy(p, &h, 2); h = f2h(scale / (18.f*2.f) * (0.5f + (float) r.uni())); memcpy(p + 2, &h, 2); break;
+            case GGML_TYPE_Q6_K: for (int i = 192; i < 208; ++i) p[i] = (uint8_t)(int8_t)((int)(p[i] & 63) - 32);   // scales in [-32,31]
+                                 h = f2h(scale / (18.5f*18.5f) * u); memcpy(p + 208, &h, 2); break;
+            default: break;
+        }
+    }
+}
+// dequantise one row of the LM head (Q6_K or Q8_0 or Q4_0): layouts of R/ggml/src/ggml-common.h:160-320
+static void dequant_row(int type, const uint8_t * row, float * y, int64_t k) {
+    if (type == GGML_TYPE_Q6_K) {
+        for (int64_t i = 0; i < k/256; ++i) {
+            const uint8_t * b = row + i*210, * ql = b, * qh = b + 128; const int8_t * sc = (const int8_t *)(b + 192);
+            uint16_t dh; memcpy(&dh, b + 208, 2); const float d = h2f(dh);
+            float * yy = y + i*256;
+            for (int n = 0; n < 2; ++n) {
+                for (int l = 0; l < 32; ++l) {
+                    const int is = l/16;
+                    const int q1 = (int)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32, q2 = (int)((ql[l+32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                    const int q3 = (int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32, q4 = (int)((ql[l+32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                    yy[l] = d*sc[is]*q1; yy[l+32] = d*sc[is+2]*q2; yy[l+64] = d*sc[is+4]*q3; yy[l+96] = d*sc[is+6]*q4;
+                }
+                yy += 128; ql += 64; qh += 32; sc += 8;
+            }
+        }
+    } else if (type == GGML_TYPE_Q8_0) {
+        for (int64_t i = 0; i < k/32; ++i) { const uint8_t * b = row + i*34; uint16_t dh; memcpy(&dh, b, 2); const float d = h2f(dh); for (int j = 0; j < 32; ++j) y[i*32+j] = d*(int8_t) b[2+j]; }
+    } else if (type == GGML_TYPE_Q4_0) {
+        for (int64_t i = 0; i < k/32; ++i) { const uint8_t * b = row + i*18; uint16_t dh; memcpy(&dh, b, 2); const float d = h2f(dh);
+            for (int j = 0; j < 16; ++j) { y[i*32+j] = d*((b[2+j] & 0xF) - 8); y[i*32+16+j] = d*((b[2+j] >> 4) - 8); } }
+    }
+}
+// fc = [ I | 0 ] in the draft's quantised type: row r has a single 1 at column r
+static void fill_identity(int type, uint8_t * dst, int64_t rows, int64_t k) {
+    const auto tr = mh::traits(type);
+    const size_t rb = mh::row_size(type, k);
+    memset(dst, 0, rows * rb);
+    for (int64_t r = 0; r < rows; ++r) {
+        uint8_t * b = dst + r*rb + (r / tr.blck) * tr.size; const int e = (int)(r % tr.blck);
+        uint16_t h;
+        if (type == GGML_TYPE_Q4_K) {                       // x = d*sc*q - dmin*m : sub-block j = e/32, sc=63 (j<4: scales[j]; else packed)
+            const int j = e / 32;
+            h = f2h(1.0f/(63*15)); memcpy(b, &h, 2);        // dmin = 0
+            if (j < 4) b[4 + j] = 63; else { b[4 + j + 4] = 63 & 0xF; b[4 + j - 4] |= (63 >> 4) << 6; }
+            const int g = e / 64, l = e % 32; const bool hi = (e % 64) >= 32;
+            b[16 + 32*g + l] |= hi ? (15 << 4) : 15;
+        } else if (type == GGML_TYPE_Q8_0) { h = f2h(1.0f/127); memcpy(b, &h, 2); b[2 + e] = 127; }
+        else if (type == GGML_TYPE_Q4_0) {                  // (q-8)*d with all other quants at 8 (zero)
+            h = f2h(1.0f/7); memcpy(b, &h, 2); memset(b + 2, 0x88, 16);
+            if (e < 16) b[2 + e] = (b[2 + e] & 0xF0) | 15; else b[2 + e - 16] = (b[2 + e - 16] & 0x0F) | (15 << 4);
+        }
+    }
+    if (type == GGML_TYPE_Q4_0) {                           // zero blocks must also decode to 0: q = 8 everywhere, d = 0
+        for (int64_t r = 0; r < rows; ++r) for (int64_t bi = 0; bi < k/32; ++bi) { uint8_t * b = dst + r*rb + bi*18; uint16_t dh; memcpy(&dh, b, 2); if (!dh) memset(b + 2, 0x88, 16); }
+    }
+}
+
+Model::~Model() {}
+
+Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const SynthOptions & opt, const Model * target) {
+    Model * m = new Model;
+    m->cfg = cfg; m->be = be;
+    m->wctx.reset(new mh::Ctx(be)); m->wctx->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+    m->gctx.reset(new mh::Ctx(be)); m->gctx->usage = GGML_BACKEND_BUFFER_USAGE_COMPUTE;
+    mh::Ctx & w = *m->wctx;
+    const int E = cfg.n_embd, KV = cfg.n_head_kv * cfg.head_dim, Q = cfg.n_head * cfg.head_dim, F = cfg.n_ff, V = cfg.n_vocab;
+    struct Pending { ggml_tensor * t; int kind; uint64_t seed; float scale; };   // kind 0 random blocks, 1 ones(f32), 2 zeros(f32), 3 identity
+    std::vector<Pending> pend;
+    uint64_t sd = opt.seed * 1000003ull + (cfg.eagle ? 7777 : 0);
+    const float tiny = opt.predictable ? 1e-4f : 1.0f;     // residual branches contribute ~nothing in the predictable model
+    auto mat = [&](const char * which, int il, int64_t k, int64_t rows, float scale, const char * name) {
+        ggml_tensor * t = w.new_tensor(weight_type_for(cfg, which, il), k, rows, 1, 1, name);
+        pend.push_back({t, 0, ++sd, scale}); m->weight_bytes += mh::nbytes(t); return t;
+    };
+    char nm[64];
+    m->layers.resize(cfg.n_layer);
+    if (cfg.eagle) {
+        m->fc = w.new_tensor(weight_type_for(cfg, "fc", 0), 2*E, E, 1, 1, "fc.weight"); m->weight_bytes += mh::nbytes(m->fc);
+        pend.push_back({m->fc, opt.predictable ? 3 : 0, ++sd, 0.02f});
+        m->fc_b = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, "fc.bias"); pend.push_back({m->fc_b, 2, 0, 0});
+    }
+    for (int il = 0; il < cfg.n_layer; ++il) {
+        Layer & L = m->layers[il];
+        if (!cfg.eagle) { snprintf(nm, sizeof nm, "blk.%d.attn_norm.weight", il); L.attn_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, nm); pend.push_back({L.attn_norm, 1, 0, 0}); }
+        snprintf(nm, sizeof nm, "blk.%d.attn_q.weight", il);      L.wq = mat("wq", il, E, Q, 0.02f, nm);
+        snprintf(nm, sizeof nm, "blk.%d.attn_k.weight", il);      L.wk = mat("wk", il, E, KV, 0.02f, nm);
+        snprintf(nm, sizeof nm, "blk.%d.attn_v.weight", il);      L.wv = mat("wv", il, E, KV, 0.02f, nm);
+        snprintf(nm, sizeof nm, "blk.%d.attn_output.weight", il); L.wo = mat("wo", il, Q, E, 0.02f * tiny, nm);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_norm.weight", il);    L.ffn_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, nm); pend.push_back({L.ffn_norm, 1, 0, 0});
+        snprintf(nm, sizeof nm, "blk.%d.ffn_gate.weight", il);    L.gate = mat("gate", il, E, F, 0.02f, nm);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_up.weight", il);      L.up = mat("up", il, E, F, 0.02f, nm);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_down.weight", il);    L.down = mat("down", il, F, E, 0.02f * tiny, nm);
+    }
+    if (!cfg.eagle) {
+        m->output_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, "output_norm.weight"); pend.push_back({m->output_norm, 1, 0, 0});
+        m->output = mat("output", 0, E, V, 0.02f, "output.weight");
+    } else {
+        m->lm_head_from = target;
+    }
+    // KV cache: f16, one tensor per layer, cleared like llama_kv_cache_init does (R/src/llama-kv-cache.cpp:27-118)
+    m->kv.init(cfg.n_ctx);
+    for (int il = 0; il < cfg.n_layer; ++il) {
+        snprintf(nm, sizeof nm, "cache_k_l%d", il); m->k_l.push_back(w.new_tensor(GGML_TYPE_F16, (int64_t) KV * cfg.n_ctx, 1, 1, 1, nm));
+        snprintf(nm, sizeof nm, "cache_v_l%d", il); m->v_l.push_back(w.new_tensor(GGML_TYPE_F16, (int64_t) KV * cfg.n_ctx, 1, 1, 1, nm));
+    }
+    if (!w.alloc()) { delete m; return nullptr; }
+    for (auto b : w.buffers) b->iface.clear(b, 0);
+
+    // fill + upload, one tensor at a time through set_tensor (what llama_model_loader::load_all_data does)
+    std::vector<uint8_t> stage;
+    std::vector<uint8_t> out_rows;                          // kept for the predictable embedding construction
+    for (auto & p : pend) {
+        const size_t n = mh::nbytes(p.t);
+        stage.resize(n);
+        if (p.kind == 0) fill_blocks(p.t->type, stage.data(), p.t->ne[1], p.t->ne[0], p.seed, p.scale);
+        else if (p.kind == 1) { float * f = (float *) stage.data(); for (size_t i = 0; i < n/4; ++i) f[i] = 1.0f; }
+        else if (p.kind == 2) memset(stage.data(), 0, n);
+        else fill_identity(p.t->type, stage.data(), p.t->ne[1], p.t->ne[0]);
+        w.set(p.t, stage.data(), 0, n);
+        if (p.t == m->output) out_rows = stage;
+    }
+    // token embeddings (host side)
+    m->tok_embd.resize((size_t) V * E);
+    Rng r(opt.seed ^ 0xABCDEF1234ull ^ (cfg.eagle ? 99 : 0));
+    if (!opt.predictable) {
+        for (size_t i = 0; i < m->tok_embd.size(); ++i) { const double u1 = r.uni() + 1e-12, u2 = r.uni(); m->tok_embd[i] = f2h((float)(std::sqrt(-2*std::log(u1)) * std::cos(6.283185307179586*u2))); }
+    } else {
+        // next(t) = perm(t):  e_t is (a multiple of) row perm(t) of the LM head, so argmax_v <W_v, norm(e_t)> = perm(t).
+        // The draft sees relu() after fc, so it gets the positive part of that row -- or, with probability 1-accept_p,
+        // of a wrong row, which makes it mispredict exactly those tokens.
+        const Model * src = cfg.eagle ? target : m;
+        std::vector<uint8_t> tgt_rows;
+        const uint8_t * rows = out_rows.data();
+        const int otype = src->output->type;
+        const size_t rb = mh::row_size(otype, E);
+        if (cfg.eagle) { tgt_rows.resize(mh::nbytes(src->output)); src->wctx->get(src->output, tgt_rows.data(), 0, tgt_rows.size()); rows = tgt_rows.data(); }
+        std::vector<int32_t> perm(V); std::iota(perm.begin(), perm.end(), 0);
+        Rng pr(opt.seed * 31 + 5);                         // same permutation for target and draft
+        for (int i = V - 1; i > 0; --i) { const int j = (int)(pr.next() % (uint64_t)(i + 1)); std::swap(perm[i], perm[j]); }
+        Rng br(opt.seed * 77 + 1);
+        std::vector<uint8_t> bad(V, 0); std::vector<int32_t> wrong(V, 0);
+        for (int t = 0; t < V; ++t) { bad[t] = cfg.eagle && br.uni() >= opt.accept_p; wrong[t] = (int32_t)(br.next() % (uint64_t) V); }
+        #pragma omp parallel
+        {
+            std::vector<float> wrow(E);
+            #pragma omp for schedule(static)
+            for (int t = 0; t < V; ++t) {
+                const int srcrow = bad[t] ? perm[wrong[t]] : perm[t];
+                dequant_row(otype, rows + (size_t) srcrow * rb, wrow.data(), E);
+                double ss = 0; for (int i = 0; i < E; ++i) ss += (double) wrow[i]*wrow[i];
+                const float a = (float)(1.0 / std::sqrt(ss / E + 1e-30));
+                for (int i = 0; i < E; ++i) { float v = wrow[i] * a; if (cfg.eagle && v < 0) v = 0; m->tok_embd[(size_t) t*E + i] = f2h(v); }
+            }
+        }
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------ decode
+int Model::decode(const Batch & b, bool want_hidden) {
+    const double t0 = now_us();
+    const int T = b.n_tokens();
+    if (T <= 0) return -1;
+    if (cfg.eagle && (int) b.hidd.size() != T * cfg.n_embd) return -2;
+    if (!kv.find_slot(b)) return 1;
+    const uint32_t pad = 32;                                 // llama_kv_cache_get_padding without flash-attn
+    kv.n = std::min(kv.size, std::max(pad, (kv.cell_max() + pad - 1) / pad * pad));
+    const int n_kv = (int) kv.n, kv_head = (int) kv.head;
+    const int E = cfg.n_embd, H = cfg.n_head, Hkv = cfg.n_head_kv, D = cfg.head_dim, n_ctx = cfg.n_ctx;
+    const int KVd = Hkv * D;
+    n_outputs = 0; out_ids.clear();
+    for (int i = 0; i < T; ++i) if (b.logits[i]) { out_ids.push_back(i); n_outputs++; }
+    if (n_outputs == 0) { out_ids.push_back(T - 1); n_outputs = 1; }
+
+    mh::Ctx & g = *gctx;
+    g.reset_graph();
+    ggml_tensor * inp_embd = g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd");
+    ggml_tensor * inp_hidd = cfg.eagle ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_hidd") : nullptr;
+    ggml_tensor * inp_pos  = g.new_tensor(GGML_TYPE_I32, T, 1, 1, 1, "inp_pos");
+    const int Tpad = (T + GGML_KQ_MASK_PAD - 1) / GGML_KQ_MASK_PAD * GGML_KQ_MASK_PAD;
+    ggml_tensor * kq_mask  = g.new_tensor(GGML_TYPE_F32, n_kv, Tpad, 1, 1, "KQ_mask");
+    ggml_tensor * inp_out  = g.new_tensor(GGML_TYPE_I32, n_outputs, 1, 1, 1, "inp_out_ids");
+    for (ggml_tensor * t : {inp_embd, inp_hidd, inp_pos, kq_mask, inp_out}) if (t) t->flags |= GGML_TENSOR_FLAG_INPUT;
+
+    ggml_tensor * inpL = inp_embd, * cur;
+    if (cfg.eagle) {                                           // build_eagle :1863-1870
+        ggml_tensor * embd_hs = g.concat(inp_embd, inp_hidd, 0);
+        cur = g.mul_mat(fc, embd_hs);
+        if (fc_b) cur = g.add(cur, fc_b);
+        inpL = g.unary(cur, GGML_UNARY_OP_RELU);
+    }
+    const float kq_scale = 1.0f / sqrtf((float) D);
+    char nm[64];
+    int n_tok = T;
+    for (int il = 0; il < cfg.n_layer; ++il) {
+        const Layer & L = layers[il];
+        ggml_tensor * inpSA = inpL;
+        cur = g.rms_norm(inpL, cfg.rms_eps);
+        if (L.attn_norm) cur = g.mul(cur, L.attn_norm);
+        snprintf(nm, sizeof nm, "attn_norm-%d", il); g.set_name(cur, nm);
+        ggml_tensor * Qcur = g.mul_mat(L.wq, cur);
+        Qcur = g.rope_ext(g.reshape(Qcur, D, H, n_tok), inp_pos, nullptr, D, 0, 0, cfg.rope_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
+        snprintf(nm, sizeof nm, "Qcur-%d", il); g.set_name(Qcur, nm);
+        ggml_tensor * Kcur = g.mul_mat(L.wk, cur);
+        Kcur = g.rope_ext(g.reshape(Kcur, D, Hkv, n_tok), inp_pos, nullptr, D, 0, 0, cfg.rope_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
+        snprintf(nm, sizeof nm, "Kcur-%d", il); g.set_name(Kcur, nm);
+        ggml_tensor * Vcur = g.mul_mat(L.wv, cur);
+        snprintf(nm, sizeof nm, "Vcur-%d", il); g.set_name(Vcur, nm);
+        // llm_build_kv_store :228-270
+        ggml_tensor * k_view = g.view_1d(k_l[il], (int64_t) n_tok * KVd, (size_t) KVd * 2 * kv_head);
+        g.cpy(Kcur, k_view);
+        ggml_tensor * v_view = g.view_2d(v_l[il], n_tok, KVd, (size_t) n_ctx * 2, (size_t) kv_head * 2);
+        g.cpy(g.transpose(Vcur), v_view);
+        // llm_build_kqv :706-828 (no flash attention)
+        ggml_tensor * q = g.permute(Qcur, 0, 2, 1, 3);
+        ggml_tensor * k = g.view_3d(k_l[il], D, n_kv, Hkv, (size_t) KVd * 2, (size_t) D * 2, 0);
+        ggml_tensor * kq = g.mul_mat(k, q);
+        kq->op_params[0] = GGML_PREC_F32;
+        kq = g.soft_max_ext(kq, kq_mask, kq_scale, 0.0f);
+        ggml_tensor * v = g.view_3d(v_l[il], n_kv, D, Hkv, (size_t) n_ctx * 2, (size_t) n_ctx * D * 2, 0);
+        ggml_tensor * kqv = g.mul_mat(v, kq);
+        cur = g.cont_2d(g.permute(kqv, 0, 2, 1, 3), (int64_t) D * H, n_tok);
+        cur = g.mul_mat(L.wo, cur);
+        if (il == cfg.n_layer - 1) {                           // skip unused tokens :1737-1743
+            n_tok = n_outputs;
+            cur = g.get_rows(cur, inp_out);
+            inpSA = g.get_rows(inpSA, inp_out);
+        }
+        ggml_tensor * ffn_inp = g.add(cur, inpSA);
+        cur = g.rms_norm(ffn_inp, cfg.rms_eps);
+        cur = g.mul(cur, L.ffn_norm);
+        ggml_tensor * gate = g.mul_mat(L.gate, cur);             // llm_build_ffn, LLM_FFN_SILU / LLM_FFN_PAR, in DFS order
+        gate = g.unary(gate, GGML_UNARY_OP_SILU);
+        ggml_tensor * up = g.mul_mat(L.up, cur);
+        cur = g.mul(gate, up);
+        cur = g.mul_mat(L.down, cur);
+        cur = g.add(cur, ffn_inp);
+        snprintf(nm, sizeof nm, "l_out-%d", il); g.set_name(cur, nm);
+        inpL = cur;
+    }
+    cur = g.rms_norm(inpL, cfg.rms_eps);
+    if (output_norm) cur = g.mul(cur, output_norm);
+    g.set_name(cur, "result_norm");
+    ggml_tensor * result_norm = cur;
+    ggml_tensor * head = cfg.eagle ? lm_head_from->output : output;
+    cur = g.mul_mat(head, cur);
+    g.set_name(cur, "result_output");
+    ggml_tensor * result_output = cur;
+    result_norm->flags |= GGML_TENSOR_FLAG_OUTPUT; result_output->flags |= GGML_TENSOR_FLAG_OUTPUT;
+    last_n_nodes = (int) g.nodes.size();
+    if (!g.alloc()) return -3;
+    const double t1 = now_us();
+
+    // ---- inputs (llama_set_inputs, R/src/llama-context.cpp:61-210)
+    static thread_local std::vector<float> embd, mask;
+    embd.resize((size_t) T * E);
+    for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; float * dst = embd.data() + (size_t) i * E; for (int j = 0; j < E; ++j) dst[j] = h2f(src[j]); }
+    g.set(inp_embd, embd.data(), 0, embd.size() * 4);
+    if (inp_hidd) g.set(inp_hidd, b.hidd.data(), 0, (size_t) T * E * 4);
+    g.set(inp_pos, b.pos.data(), 0, (size_t) T * 4);
+    g.set(inp_out, out_ids.data(), 0, (size_t) n_outputs * 4);
+    mask.assign((size_t) n_kv * Tpad, -INFINITY);
+    for (int j = 0; j < T; ++j) {
+        const uint64_t sbit = 1ull << b.seq_first[j]; const int32_t pos = b.pos[j];
+        float * row = mask.data() + (size_t) j * n_kv;
+        for (int i = 0; i < n_kv; ++i) if ((kv.cells[i].seqs & sbit) && kv.cells[i].pos <= pos) row[i] = 0.0f;
+    }
+    g.set(kq_mask, mask.data(), 0, mask.size() * 4);
+    const double t2 = now_us();
+
+    const enum ggml_status st = g.compute();
+    const double t3 = now_us();
+    if (st != GGML_STATUS_SUCCESS) { return st == GGML_STATUS_ABORTED ? 2 : -4; }
+
+    // ---- outputs
+    logits.resize((size_t) n_outputs * cfg.n_vocab);
+    g.get(result_output, logits.data(), 0, logits.size() * 4);
+    if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get(result_norm, hidden.data(), 0, hidden.size() * 4); }
+    kv.head += T;
+    if (kv.head >= kv.size) kv.head = 0;
+    const double t4 = now_us();
+    t_build_us += t1 - t0; t_upload_us += t2 - t1; t_compute_us += t3 - t2; t_download_us += t4 - t3; n_decode++;
+    return 0;
+}
+
+const float * Model::logits_ith(int i) const { for (int r = 0; r < n_outputs; ++r) if (out_ids[r] == i) return logits.data() + (size_t) r * cfg.n_vocab; return nullptr; }
+const float * Model::hidden_ith(int i) const { for (int r = 0; r < n_outputs; ++r) if (out_ids[r] == i) return hidden.data() + (size_t) r * cfg.n_embd; return nullptr; }
+
+} // namespace eh

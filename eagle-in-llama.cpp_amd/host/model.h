@@ -1,0 +1,99 @@
+// model.h -- host-side mirror of the reference's decode path for the llama / eagle architectures:
+//   KV-cell bookkeeping           R/src/llama-kv-cache.cpp (find_slot :286-336, seq_rm :368, seq_cp :431, seq_keep :478, cell_max :338)
+//   mask / input upload           R/src/llama-context.cpp:61-210 (llama_set_inputs)
+//   graph builders                R/src/llama.cpp build_llama :1647, build_eagle :1839, build_lmhead :1813,
+//                                 llm_build_{norm :329, fc :367, ffn :456, kv_store :228, kqv :706, kv :830}
+//   decode entry points           llama_decode_impl :9486, llama_decode_draft_impl :9978 (hidden-state channel)
+// The graphs are emitted node for node in the order ggml_build_forward_expand would give them, with the
+// reference's tensor names, and are executed through the backend vtables only (minihost.h).
+#pragma once
+#include "minihost.h"
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace eh {
+
+enum Ftype { FTYPE_Q4_0 = 0, FTYPE_Q4_K_M = 1, FTYPE_Q8_0 = 2 };
+
+struct ModelConfig {
+    int n_embd = 4096, n_head = 32, n_head_kv = 32, head_dim = 128, n_ff = 11008, n_layer = 32, n_vocab = 32000;
+    float rms_eps = 1e-6f, rope_base = 10000.0f;
+    int n_ctx = 2048;
+    int ftype = FTYPE_Q4_K_M;
+    bool eagle = false;               // EAGLE head: fc [2*n_embd -> n_embd] + bias + ReLU, no attn_norm / output_norm weights
+    int n_seq_max = 16;
+};
+
+struct Batch {                          // llama_batch: token, pos, seq ids, logits flag (R/include/llama.h:236-253)
+    std::vector<int32_t>  token;
+    std::vector<int32_t>  pos;
+    std::vector<int32_t>  seq_first;    // seq_id[t][0] -- decides the mask row
+    std::vector<uint64_t> seq_mask;     // all seq ids of the token as a bit set
+    std::vector<uint8_t>  logits;       // output wanted for this token
+    std::vector<float>    hidd;         // optional [n_tokens][n_embd] (llama_batch.hidd, llama.h:252)
+    int n_tokens() const { return (int) token.size(); }
+    void clear() { token.clear(); pos.clear(); seq_first.clear(); seq_mask.clear(); logits.clear(); hidd.clear(); }
+    void add(int32_t tok, int32_t p, int32_t seq, bool want_logits) { token.push_back(tok); pos.push_back(p); seq_first.push_back(seq); seq_mask.push_back(1ull << seq); logits.push_back(want_logits); }
+};
+
+struct KVCache {
+    struct Cell { int32_t pos = -1; uint64_t seqs = 0; };
+    uint32_t size = 0, head = 0, n = 0, used = 0;
+    std::vector<Cell> cells;
+    void init(uint32_t sz) { size = sz; head = 0; n = 0; used = 0; cells.assign(sz, Cell()); }
+    bool find_slot(const Batch & b);
+    uint32_t cell_max() const;
+    void seq_rm(int seq, int32_t p0, int32_t p1);
+    void seq_cp(int src, int dst, int32_t p0, int32_t p1);
+    void seq_keep(int seq);
+    void clear() { for (auto & c : cells) c = Cell(); head = 0; used = 0; }
+};
+
+struct Layer { ggml_tensor * attn_norm = nullptr, * wq = nullptr, * wk = nullptr, * wv = nullptr, * wo = nullptr,
+               * ffn_norm = nullptr, * gate = nullptr, * up = nullptr, * down = nullptr; };
+
+struct SynthOptions {
+    uint64_t seed = 42;
+    float accept_p = 0.8f;            // fraction of tokens whose draft embedding predicts the target's next token
+    bool  predictable = true;         // structured weights (see model.cpp); false = plain random blocks
+};
+
+struct Model {
+    ModelConfig cfg;
+    mh::Backend * be = nullptr;
+    std::unique_ptr<mh::Ctx> wctx;    // weights (+ KV cache tensors)
+    std::unique_ptr<mh::Ctx> gctx;    // per-decode graph, buffer re-used between calls
+    std::vector<Layer> layers;
+    ggml_tensor * output_norm = nullptr, * output = nullptr, * fc = nullptr, * fc_b = nullptr;
+    std::vector<uint16_t> tok_embd;   // host-resident f16 [n_vocab][n_embd] (the reference keeps token_embd on the CPU too:
+                                      // R/src/llama-model.cpp:1339-1341)
+    std::vector<ggml_tensor *> k_l, v_l;
+    KVCache kv;
+    const Model * lm_head_from = nullptr;   // EAGLE: LM head borrowed from the target (build_lmhead on llm2)
+    size_t weight_bytes = 0;          // bytes of all mat-mul weights resident on the device (for the roofline)
+
+    // outputs of the last decode
+    std::vector<float> logits;        // [n_outputs][n_vocab]
+    std::vector<float> hidden;        // [n_outputs][n_embd]  (result_norm rows: the hidden-state channel)
+    std::vector<int32_t> out_ids;     // batch index of each output row
+    int n_outputs = 0;
+    // timing / stats
+    double t_build_us = 0, t_upload_us = 0, t_compute_us = 0, t_download_us = 0; int64_t n_decode = 0;
+    int last_n_nodes = 0;
+
+    static Model * create_synthetic(mh::Backend * be, const ModelConfig & cfg, const SynthOptions & opt, const Model * target /* for eagle */);
+    ~Model();
+    // llama_decode / llama_decode_draft: 0 ok, 1 no KV slot, <0 error (R/src/llama.cpp:9610-9617)
+    int decode(const Batch & batch, bool want_hidden);
+    const float * logits_ith(int i) const;      // by batch index, like llama_get_logits_ith
+    const float * hidden_ith(int i) const;
+    size_t matmul_weight_bytes() const { return weight_bytes; }
+};
+
+// per-type byte size of a row
+size_t row_bytes(int type, int64_t k);
+int    weight_type_for(const ModelConfig & cfg, const char * which, int il);
+
+} // namespace eh

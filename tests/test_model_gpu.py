@@ -1,0 +1,60 @@
+"""End-to-end parity on a real MI355X: the SAME host graphs (build_llama / build_eagle mirrors) and the SAME
+speculative driver run on our plugin and on the reference CPU backend (oracle/_ref) -- logits within 1e-3
+relative (BASELINE.json north_star), generated / accepted token indices identical."""
+import numpy as np
+import pytest
+
+from conftest import have_ref
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")]
+
+
+def rel(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / (np.abs(b.astype(np.float64)).max() + 1e-30))
+
+
+@pytest.mark.parametrize("ftype", ["q4_k_m", "q8_0", "q4_0"])
+@pytest.mark.parametrize("config", ["tiny", "tiny-gqa"])
+def test_logits_match_reference_cpu(ea, gpu, ref_cpu, ftype, config):
+    """random (non-degenerate) weights: prompt batch, single-token steps and a tree-verify batch with shared positions"""
+    outs = []
+    for be in (gpu, ref_cpu):
+        m = ea.Model(be, config, ftype, n_ctx=256, seed=3, predictable=False)
+        d = ea.Model(be, config, ftype, n_ctx=256, eagle_of=m, seed=3, predictable=False)
+        res = []
+        lg, hid = m.decode(list(range(5, 21)), list(range(16)))                     # prompt, 16 tokens, all outputs
+        res += [lg, hid]
+        lg1, hid1 = m.decode([77], [16]); res += [lg1, hid1]                        # T = 1
+        # tree verify: two branches (seq 1, 2) forking after position 16: tokens at the same positions
+        m.kv_seq_rm(0, 17, -1)
+        import ctypes as C
+        from conftest import load_package
+        h = load_package()._model_sigs()
+        h.eh_model_kv_seq_cp(m.h, 0, 1, -1, -1); h.eh_model_kv_seq_cp(m.h, 0, 2, -1, -1)
+        lgt, hidt = m.decode([10, 11, 12, 13, 14], [17, 18, 17, 18, 19], seq=[1, 1, 2, 2, 2]); res += [lgt, hidt]
+        # EAGLE head: features in, logits through the target's LM head
+        lgd, hidd = d.decode([30, 31, 32], [1, 2, 3], hidd=hid[:3]); res += [lgd, hidd]
+        lgd2, _ = d.decode([33], [4], hidd=hidd[2:3]); res += [lgd2]
+        outs.append(res)
+        d.close(); m.close()
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert a.shape == b.shape
+        assert rel(a, b) < 1e-3, (i, rel(a, b))
+        if a.shape[-1] in (512, 768):                                               # logits rows: same argmax
+            assert np.array_equal(a.argmax(-1), b.argmax(-1)), i
+
+
+@pytest.mark.parametrize("ftype", ["q4_k_m", "q8_0"])
+def test_speculative_tokens_and_acceptance_identical(ea, gpu, ref_cpu, ftype):
+    seqs = []
+    for be in (gpu, ref_cpu):
+        t = ea.Model(be, "tiny", ftype, n_ctx=512, seed=11)
+        d = ea.Model(be, "tiny", ftype, n_ctx=512, eagle_of=t, seed=11, accept_p=0.75)
+        prompt = [int(x) for x in np.random.default_rng(1234).integers(5, 512, 32)]
+        plain, _ = ea.plain_generate(t, prompt, 96)
+        spec, st = ea.spec_generate(t, d, prompt, 96, n_draft=5)
+        assert plain == spec[:len(plain)]                     # speculation never changes the greedy output
+        seqs.append((spec, st["n_accept"], st["n_drafted"], st["n_iters"]))
+        d.close(); t.close()
+    assert seqs[0] == seqs[1]                                 # accepted-token indices bit-exact vs the reference CPU path
+    assert seqs[0][1] > 0
