@@ -106,7 +106,13 @@ class Backend:
         p = REF_GGML_SCALAR_PATH if scalar else REF_GGML_PATH
         if not os.path.exists(p):
             raise FileNotFoundError(f"{p} not built (make -C oracle ref; needs /root/reference)")
-        return Backend(p, "ggml_backend_cpu_reg", 0, threads or (os.cpu_count() or 4))
+        if threads is None:      # cores this process may actually use (a GPU box exposes many more than its share), capped
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except AttributeError:
+                threads = os.cpu_count() or 4
+            threads = max(1, min(threads, 16))
+        return Backend(p, "ggml_backend_cpu_reg", 0, threads)
 
     @property
     def name(self):

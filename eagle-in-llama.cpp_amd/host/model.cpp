@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <cstdlib>
 
 namespace eh {
 
@@ -105,11 +106,21 @@ static void fill_blocks(int type, uint8_t * dst, int64_t rows, int64_t k, uint64
         for (int i = 0; i < tr.size; i += 8) { uint64_t v = r.next(); memcpy(p + i, &v, std::min(8, tr.size - i)); }
         const float u = 0.5f + (float) r.uni();
         uint16_t h;
+        // zero-mean weights: K-quants use min = 7.5 (15.5) * scale per sub-block, i.e. x = d*sc*(q - 7.5);
+        // Q4_0 (x = d*(q-8), mean -0.5 d) gets a random sign on d.
+        auto k4_scales = [&](uint8_t * sc12) {            // encode sc_j == m_j (6 bits each) in the packed 12-byte field
+            uint8_t s6[8]; for (int j = 0; j < 8; ++j) s6[j] = (uint8_t)(r.next() & 63);
+            for (int j = 0; j < 4; ++j) {
+                sc12[j]     = (uint8_t)((s6[j] & 63) | ((s6[j + 4] >> 4) << 6));
+                sc12[j + 4] = (uint8_t)((s6[j] & 63) | ((s6[j + 4] >> 4) << 6));
+                sc12[j + 8] = (uint8_t)((s6[j + 4] & 0xF) | ((s6[j + 4] & 0xF) << 4));
+            }
+        };
         switch (type) {
-            case GGML_TYPE_Q4_0: h = f2h(scale / 4.6f * u); memcpy(p, &h, 2); break;                          // q-8 uniform: std 4.6
-            case GGML_TYPE_Q8_0: h = f2h(scale / 74.f * u); memcpy(p, &h, 2); break;                          // int8 uniform: std 74
-            case GGML_TYPE_Q4_K: h = f2h(scale / (18.f*4.6f) * u); memcpy(p, &h, 2); h = f2h(scale / (18.f*2.f) * (0.5f + (float) r.uni())); memcpy(p + 2, &h, 2); break;
-            case GGML_TYPE_Q5_K: h = f2h(scale / (18.f*9.2f) * u); memcpy(p, &h, 2); h = f2h(scale / (18.f*2.f) * (0.5f + (float) r.uni())); memcpy(p + 2, &h, 2); break;
+            case GGML_TYPE_Q4_0: h = f2h(scale / 4.6f * u * ((r.next() & 1) ? 1.f : -1.f)); memcpy(p, &h, 2); break;   // q-8 uniform: std 4.6
+            case GGML_TYPE_Q8_0: h = f2h(scale / 74.f * u); memcpy(p, &h, 2); break;                                      // int8 uniform: std 74
+            case GGML_TYPE_Q4_K: { const float d = scale / (18.f*4.6f) * u; h = f2h(d); memcpy(p, &h, 2); h = f2h(7.5f * h2f(h)); memcpy(p + 2, &h, 2); k4_scales(p + 4); } break;
+            case GGML_TYPE_Q5_K: { const float d = scale / (18.f*9.2f) * u; h = f2h(d); memcpy(p, &h, 2); h = f2h(15.5f * h2f(h)); memcpy(p + 2, &h, 2); k4_scales(p + 4); } break;
             case GGML_TYPE_Q6_K: for (int i = 192; i < 208; ++i) p[i] = (uint8_t)(int8_t)((int)(p[i] & 63) - 32);   // scales in [-32,31]
                                  h = f2h(scale / (18.5f*18.5f) * u); memcpy(p + 208, &h, 2); break;
             default: break;
@@ -177,7 +188,7 @@ Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const
     struct Pending { ggml_tensor * t; int kind; uint64_t seed; float scale; };   // kind 0 random blocks, 1 ones(f32), 2 zeros(f32), 3 identity
     std::vector<Pending> pend;
     uint64_t sd = opt.seed * 1000003ull + (cfg.eagle ? 7777 : 0);
-    const float tiny = opt.predictable ? 1e-4f : 1.0f;     // residual branches contribute ~nothing in the predictable model
+    const float tiny = opt.predictable ? (getenv("EH_TINY") ? (float) atof(getenv("EH_TINY")) : 1e-4f) : 1.0f;     // residual branches contribute ~nothing in the predictable model
     auto mat = [&](const char * which, int il, int64_t k, int64_t rows, float scale, const char * name) {
         ggml_tensor * t = w.new_tensor(weight_type_for(cfg, which, il), k, rows, 1, 1, name);
         pend.push_back({t, 0, ++sd, scale}); m->weight_bytes += mh::nbytes(t); return t;
