@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0, 'tests')
+import sys, os, time; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from conftest import load_package
 import numpy as np
 ea = load_package()

@@ -1,5 +1,5 @@
 """Small workload for rocprofv3: Vicuna-7B-shaped Q4_K_M target + EAGLE head, a few plain steps and a few speculative rounds."""
-import sys; sys.path.insert(0, 'tests')
+import sys, os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from conftest import load_package
 import numpy as np
 ea = load_package()
