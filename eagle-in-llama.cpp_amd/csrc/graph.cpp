@@ -2,14 +2,20 @@
 // (R/ggml/src/ggml-backend.cpp:1397) and launches hand-written gfx950 kernels, fusing the node
 // sequences build_llama / build_eagle emit (R/src/llama.cpp:1647-2019) so that the launch count per
 // transformer layer drops from ~25 to ~10:
-//     RMS_NORM -> MUL(weight)                  one kernel
-//     MUL_MAT(quantised) -> ADD(residual)      residual added in the mat-vec epilogue
-//     UNARY(SILU) -> MUL                       one kernel
-//     MUL_MAT(K,q) -> SOFT_MAX -> MUL_MAT(V,p) [-> PERMUTE -> CONT]   one attention kernel (small batches)
+//     [RMS_NORM -> MUL(w)] -> {MUL_MAT wq -> ROPE | MUL_MAT wk -> ROPE -> CPY(K cache) | MUL_MAT wv -> CPY(V^T cache)}   1 launch
+//     MUL_MAT(K,q) -> SOFT_MAX(tree mask) -> MUL_MAT(V,p) -> PERMUTE -> CONT                                          1 launch
+//     MUL_MAT(wo) -> ADD(residual)                                                                                    1 launch
+//     [RMS_NORM -> MUL(w)] -> {MUL_MAT gate -> SILU, MUL_MAT up} -> MUL                                               1 launch
+//     MUL_MAT(down) -> ADD(residual)                                                                                  1 launch
+// i.e. 5 launches per transformer layer instead of ~22 nodes.  A fusion that would move a write earlier than its
+// node's position is only taken when the written range cannot alias anything the skipped-over nodes touch
+// (ggml-alloc re-uses memory), otherwise the nodes run one by one.
 // Reference counterpart: ggml_cuda_compute_forward (R/ggml/src/ggml-cuda/ggml-cuda.cu:2096) which
 // launches one kernel (or more) per node.  supports_op mirrors the role of :2946-3229.
 #include "kernels.h"
 #include <vector>
+#include <algorithm>
+#include <cmath>
 
 static inline bool is_view_op(int op) {
     return op == GGML_OP_NONE || op == GGML_OP_RESHAPE || op == GGML_OP_VIEW || op == GGML_OP_PERMUTE || op == GGML_OP_TRANSPOSE;
@@ -71,66 +77,353 @@ bool mi_supports_op(int, const ggml_tensor * op) {
     }
 }
 
-// ---- use counts (how many later nodes read a tensor), pointer-keyed open addressing
-struct use_map {
-    std::vector<const ggml_tensor *> key; std::vector<int> cnt; size_t mask;
-    explicit use_map(size_t n) { size_t s = 64; while (s < 4*n) s <<= 1; key.assign(s, nullptr); cnt.assign(s, 0); mask = s - 1; }
+// ---- per-graph side tables, pointer-keyed open addressing
+struct tmap {
+    std::vector<const ggml_tensor *> key; std::vector<int> a, b; size_t mask;
+    explicit tmap(size_t n) { size_t s = 64; while (s < 4*n) s <<= 1; key.assign(s, nullptr); a.assign(s, 0); b.assign(s, -1); mask = s - 1; }
     size_t slot(const ggml_tensor * t) const { size_t h = ((uintptr_t) t >> 4) * 0x9E3779B97F4A7C15ull; size_t i = (h >> 20) & mask; while (key[i] && key[i] != t) i = (i + 1) & mask; return i; }
-    void add(const ggml_tensor * t) { size_t i = slot(t); key[i] = t; cnt[i]++; }
-    int  get(const ggml_tensor * t) const { size_t i = slot(t); return key[i] ? cnt[i] : 0; }
+    size_t touch(const ggml_tensor * t) { size_t i = slot(t); key[i] = t; return i; }
+    bool has(const ggml_tensor * t, size_t & i) const { i = slot(t); return key[i] != nullptr; }
 };
-// a view chain (RESHAPE/VIEW/PERMUTE/TRANSPOSE) resolves to the tensor that owns the data
-static const ggml_tensor * view_root(const ggml_tensor * t) { while (t && is_view_op(t->op) && t->src[0] && t->op != GGML_OP_NONE) t = t->src[0]; return t; }
+static inline const ggml_tensor * root_of(const ggml_tensor * t) { return t->view_src ? t->view_src : t; }
 
-static bool try_fuse_attention(mi_backend_ctx * ctx, ggml_cgraph * g, int i, const use_map & uses, int * consumed);
+struct gctx {
+    ggml_cgraph * g; int n;
+    tmap uses;        // a = number of nodes that read the tensor directly, b = index of the LAST such node
+    tmap rootlast;    // keyed by data owner: b = index of the last node reading it through any view
+    tmap index;       // b = node index of a tensor
+    std::vector<char> done;
+    explicit gctx(ggml_cgraph * gr) : g(gr), n(gr->n_nodes), uses((size_t) gr->n_nodes*3 + 16), rootlast((size_t) gr->n_nodes*3 + 16), index((size_t) gr->n_nodes + 16), done(gr->n_nodes, 0) {
+        for (int i = 0; i < n; ++i) {
+            const ggml_tensor * t = g->nodes[i];
+            index.b[index.touch(t)] = i;
+            for (int s = 0; s < GGML_MAX_SRC; ++s) if (t->src[s]) {
+                size_t u = uses.touch(t->src[s]); uses.a[u]++; uses.b[u] = i;
+                size_t r = rootlast.touch(root_of(t->src[s])); rootlast.b[r] = i;
+            }
+        }
+    }
+    int n_uses(const ggml_tensor * t) const { size_t i; return uses.has(t, i) ? uses.a[i] : 0; }
+    int last_use(const ggml_tensor * t) const { size_t i; return uses.has(t, i) ? uses.b[i] : -1; }
+    int root_last_read(const ggml_tensor * t) const { size_t i; return rootlast.has(root_of(t), i) ? rootlast.b[i] : -1; }
+    int idx(const ggml_tensor * t) const { size_t i; return index.has(t, i) ? index.b[i] : -1; }
+    // the single node that consumes t, looking through view ops (RESHAPE/PERMUTE/TRANSPOSE/VIEW); nullptr if not unique
+    ggml_tensor * sole_consumer(const ggml_tensor * t, bool through_views) const {
+        for (int hop = 0; hop < 4; ++hop) {
+            if (n_uses(t) != 1 || (t->flags & GGML_TENSOR_FLAG_OUTPUT)) return nullptr;
+            ggml_tensor * c = g->nodes[last_use(t)];
+            if (through_views && is_view_op(c->op) && c->op != GGML_OP_NONE) { t = c; continue; }
+            return c;
+        }
+        return nullptr;
+    }
+};
+static inline bool overlap(const void * p, size_t n, const void * q, size_t m) { return p && q && (const char *) p < (const char *) q + m && (const char *) q < (const char *) p + n; }
+// would writing [p, p+n) at position `at` disturb a node in (at, upto) that still has to run?  (nodes flagged in `skip` do not run)
+static bool write_conflicts(const gctx & c, const void * p, size_t n, int at, int upto, const std::vector<char> & skip) {
+    for (int j = at + 1; j < upto; ++j) {
+        if (skip[j]) continue;
+        const ggml_tensor * t = c.g->nodes[j];
+        if (overlap(p, n, t->data, mi_nbytes(t))) return true;
+        for (int s = 0; s < GGML_MAX_SRC; ++s) if (t->src[s] && overlap(p, n, t->src[s]->data, mi_nbytes(t->src[s]))) return true;
+    }
+    return false;
+}
+static inline bool name_is_result(const ggml_tensor * t) { return strncmp(t->name, "result_", 7) == 0; }
+
+// ---- activation source of a quantised mat-mul: x itself, or RMS_NORM(a) [* w] folded into the prologue
+struct act_plan { act_src src; const ggml_tensor * rms = nullptr, * mul = nullptr; };
+static bool plan_act(const gctx & c, const ggml_tensor * x, int k, int n_members_using_x, int last_member, act_plan & p) {
+    p = act_plan();
+    p.src.X = (const float *) x->data; p.src.xs = x->nb[1]/4; p.src.norm = 0; p.src.norm_w = nullptr; p.src.eps = 0;
+    const ggml_tensor * rms = nullptr, * mul = nullptr, * w = nullptr;
+    if (x->op == GGML_OP_MUL && x->src[0] && x->src[0]->op == GGML_OP_RMS_NORM) { mul = x; rms = x->src[0]; w = x->src[1]; }
+    else if (x->op == GGML_OP_RMS_NORM) rms = x;
+    if (!rms) return true;
+    const int ir = c.idx(rms), im = mul ? c.idx(mul) : -1;
+    if (ir < 0 || c.done[ir] != 2) return true;                       // 2 = deferred by the RMS_NORM visit below
+    (void) im; (void) n_members_using_x; (void) last_member;
+    const ggml_tensor * a = rms->src[0];
+    p.src.X = (const float *) a->data; p.src.xs = a->nb[1]/4; p.src.norm = 1; p.src.eps = mi_op_f32(rms, 0);
+    p.src.norm_w = w ? (const float *) w->data : nullptr;
+    p.rms = rms; p.mul = mul;
+    (void) k;
+    return true;
+}
+// Can RMS_NORM at node i (optionally followed by MUL with a weight row) be left to its consumers' prologues?
+static bool can_defer_norm(const gctx & c, int i) {
+    const ggml_tensor * rms = c.g->nodes[i];
+    const ggml_tensor * a = rms->src[0];
+    if (!is_f32(a) || a->nb[0] != 4 || a->ne[2] != 1 || a->ne[3] != 1 || (a->nb[1] % 16) || ((uintptr_t) a->data % 16)) return false;
+    if ((rms->flags & GGML_TENSOR_FLAG_OUTPUT) || name_is_result(rms)) return false;
+    const ggml_tensor * x = rms;
+    if (c.n_uses(rms) == 1) {
+        const ggml_tensor * m = c.g->nodes[c.last_use(rms)];
+        if (m->op == GGML_OP_MUL && m->src[0] == rms && c.idx(m) == i + 1) {
+            const ggml_tensor * w = m->src[1];
+            if (!is_f32(w) || w->ne[0] != rms->ne[0] || mi_nrows(w) != 1 || w->nb[0] != 4 || ((uintptr_t) w->data % 16)) return false;
+            if ((m->flags & GGML_TENSOR_FLAG_OUTPUT) || name_is_result(m)) return false;
+            x = m;
+        }
+    }
+    // every reader of x must be a quantised mat-mul we run with mmvq (x as src1), and `a` must outlive them all
+    const int nu = c.n_uses(x);
+    if (nu < 1) return false;
+    int found = 0, last = -1;
+    for (int j = c.idx(x) + 1; j < c.n && found < nu; ++j) {
+        const ggml_tensor * t = c.g->nodes[j];
+        bool reads = false;
+        for (int s = 0; s < GGML_MAX_SRC; ++s) if (t->src[s] == x) reads = true;
+        if (!reads) continue;
+        if (t->op != GGML_OP_MUL_MAT || t->src[1] != x || !mi_mul_mat_q_supported_type(t->src[0]->type) || t->src[0]->ne[2] != 1 || t->src[0]->ne[3] != 1) return false;
+        if (!mi_supports_op(0, t)) return false;
+        found++; last = j;
+    }
+    if (found != nu) return false;
+    if (c.root_last_read(a) <= last) {
+        // `a` is not read after the last consumer: its memory may already have been handed to a node in between
+        std::vector<char> none(c.n, 0);
+        for (int j = i + 1; j <= last; ++j) { const ggml_tensor * t = c.g->nodes[j]; if (overlap(a->data, mi_nbytes(a), t->data, mi_nbytes(t)) && !is_view_op(t->op)) return false; }
+    }
+    return true;
+}
+
+// ---- one member of a multi-matrix mat-vec launch and the nodes its epilogue swallows
+struct member {
+    int node = -1; const ggml_tensor * mm = nullptr;
+    int epi = EPI_F32; const ggml_tensor * out = nullptr;            // tensor that receives the result
+    const ggml_tensor * res = nullptr;                                // residual for EPI_F32
+    const ggml_tensor * rope = nullptr;
+    std::vector<int> swallowed;                                       // node indices done by this member
+};
+static bool rope_fusable(const ggml_tensor * r, const ggml_tensor * mm) {
+    if (r->op != GGML_OP_ROPE || !is_f32(r) || r->src[2]) return false;
+    if (mi_op_i32(r, 2) != 0 || mi_op_f32(r, 7) != 0.0f) return false;               // mode NORM, no YaRN mixing
+    if (mi_op_i32(r, 1) != r->ne[0] || (r->ne[0] % 2)) return false;                  // n_dims == head size
+    if (r->ne[0]*r->ne[1] != mm->ne[0] || r->ne[2] != mm->ne[1] || r->ne[3] != 1) return false;
+    if (!mi_is_contiguous(r) || r->src[1]->type != GGML_TYPE_I32) return false;
+    return true;
+}
+// follow mm's result: [RESHAPE] -> ROPE -> (CPY to f16 cache)?  |  [TRANSPOSE] -> CPY f16  |  ADD residual  |  plain
+static void plan_member(const gctx & c, member & m) {
+    const ggml_tensor * mm = m.mm;
+    m.epi = EPI_F32; m.out = mm; m.res = nullptr; m.rope = nullptr; m.swallowed.clear();
+    if ((mm->flags & GGML_TENSOR_FLAG_OUTPUT) || c.n_uses(mm) != 1) return;
+    const ggml_tensor * c1 = c.g->nodes[c.last_use(mm)];
+    // optional reshape
+    const ggml_tensor * v = c1; std::vector<int> sw;
+    if (v->op == GGML_OP_RESHAPE && v->src[0] == mm && c.n_uses(v) == 1 && !(v->flags & GGML_TENSOR_FLAG_OUTPUT)) { sw.push_back(c.idx(v)); v = c.g->nodes[c.last_use(v)]; }
+    if (v->op == GGML_OP_ROPE && rope_fusable(v, mm) && (v->src[0] == mm || (sw.size() && v->src[0] == c.g->nodes[sw.back()]))) {
+        const ggml_tensor * rope = v;
+        // K: rope -> CPY into an f16 view (contiguous token-major slice of the cache)
+        if (c.n_uses(rope) == 1 && !(rope->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+            const ggml_tensor * cp = c.g->nodes[c.last_use(rope)];
+            if (cp->op == GGML_OP_CPY && cp->src[0] == rope && cp->src[1]->type == GGML_TYPE_F16 && mi_is_contiguous(cp->src[1]) &&
+                mi_nelements(cp->src[1]) == mi_nelements(rope)) {
+                m.epi = EPI_ROPE_F16; m.out = cp->src[1]; m.rope = rope; m.swallowed = sw; m.swallowed.push_back(c.idx(rope)); m.swallowed.push_back(c.idx(cp));
+                return;
+            }
+        }
+        m.epi = EPI_ROPE_F32; m.out = rope; m.rope = rope; m.swallowed = sw; m.swallowed.push_back(c.idx(rope));
+        return;
+    }
+    // V: [TRANSPOSE] -> CPY into an f16 [T, rows] view with arbitrary row stride
+    if (c1->op == GGML_OP_TRANSPOSE && c1->src[0] == mm && c.n_uses(c1) == 1) {
+        const ggml_tensor * cp = c.g->nodes[c.last_use(c1)];
+        if (cp->op == GGML_OP_CPY && cp->src[0] == c1 && cp->src[1]->type == GGML_TYPE_F16 && cp->src[1]->ne[0] == mm->ne[1] && cp->src[1]->ne[1] == mm->ne[0] &&
+            cp->src[1]->ne[2] == 1 && cp->src[1]->ne[3] == 1 && cp->src[1]->nb[0] == 2) {
+            m.epi = EPI_F16; m.out = cp->src[1]; m.swallowed.push_back(c.idx(c1)); m.swallowed.push_back(c.idx(cp));
+            return;
+        }
+    }
+    // residual: the very next node adds a same-shaped f32 tensor
+    if (c1->op == GGML_OP_ADD && c.idx(c1) == m.node + 1 && is_f32(c1) && c1->nb[0] == 4 && mi_same_shape(c1, mm)) {
+        const ggml_tensor * other = c1->src[0] == mm ? c1->src[1] : c1->src[0];
+        if (other != mm && is_f32(other) && mi_same_shape(other, mm) && other->nb[0] == 4) { m.res = other; m.out = c1; m.swallowed.push_back(c.idx(c1)); }
+    }
+}
+static void fill_mat(mmvq_mat & M, const member & m) {
+    const ggml_tensor * w = m.mm->src[0];
+    M.W = (const char *) w->data; M.row_bytes = w->nb[1]; M.rows = (int) w->ne[1]; M.epi = m.epi; M.res = nullptr; M.r_tok = 0;
+    M.out = (char *) m.out->data;
+    switch (m.epi) {
+        case EPI_F32:      M.o_row = 4; M.o_tok = m.out->nb[1]; if (m.res) { M.res = (const float *) m.res->data; M.r_tok = m.res->nb[1]/4; } break;
+        case EPI_ROPE_F32: M.o_row = 4; M.o_tok = (int64_t) w->ne[1] * 4; break;                         // rope out is contiguous [d, heads, T]
+        case EPI_ROPE_F16: M.o_row = 2; M.o_tok = (int64_t) w->ne[1] * 2; break;                         // contiguous f16 slice
+        case EPI_F16:      M.o_row = m.out->nb[1]; M.o_tok = 2; break;                                   // out [T, rows]: token fastest
+    }
+}
+
+// try to run MUL_MAT node i together with its siblings; returns true when handled
+static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
+    ggml_tensor * t = c.g->nodes[i];
+    const ggml_tensor * w0 = t->src[0], * x = t->src[1];
+    hipStream_t st = ctx->stream;
+    const bool simple2d = w0->ne[2] == 1 && w0->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1;
+    if (!fuse || !simple2d) {
+        // RMS_NORM deferred to us?  only possible when fuse is on, so nothing to undo here
+        const ggml_tensor * res = nullptr; ggml_tensor * nx = (i + 1 < c.n) ? c.g->nodes[i + 1] : nullptr;
+        if (fuse && nx && nx->op == GGML_OP_ADD && c.n_uses(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT) && is_f32(nx) && nx->nb[0] == 4 && mi_same_shape(nx, t)) {
+            if      (nx->src[0] == t && is_f32(nx->src[1]) && mi_same_shape(nx->src[1], t) && nx->src[1]->nb[0] == 4) res = nx->src[1];
+            else if (nx->src[1] == t && is_f32(nx->src[0]) && mi_same_shape(nx->src[0], t) && nx->src[0]->nb[0] == 4) res = nx->src[0];
+        }
+        if (res) { mi_op_mul_mat_q(st, t, res, nx); c.done[i + 1] = 1; } else mi_op_mul_mat_q(st, t, nullptr, t);
+        return true;
+    }
+    const int k = (int) w0->ne[0], T = (int) x->ne[1];
+    // ---- collect siblings: later MUL_MATs with the same src1, same weight type
+    member mem[3]; int nm = 0;
+    mem[nm].node = i; mem[nm].mm = t; nm++;
+    for (int j = i + 1; j < c.n && j < i + 14 && nm < 3; ++j) {
+        const ggml_tensor * u = c.g->nodes[j];
+        if (c.done[j] || u->op != GGML_OP_MUL_MAT || u->src[1] != x) continue;
+        if (u->src[0]->type != w0->type || u->src[0]->ne[0] != k || u->src[0]->ne[2] != 1 || u->src[0]->ne[3] != 1 || !mi_supports_op(0, u)) continue;
+        mem[nm].node = j; mem[nm].mm = u; nm++;
+    }
+    // ---- SwiGLU: gate (this node) -> SILU -> MUL(silu, up)
+    if (nm >= 2 && c.n_uses(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+        const ggml_tensor * silu = c.g->nodes[c.last_use(t)];
+        if (silu->op == GGML_OP_UNARY && mi_op_i32(silu, 0) == GGML_UNARY_OP_SILU && c.n_uses(silu) == 1 && !(silu->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+            const ggml_tensor * mul = c.g->nodes[c.last_use(silu)];
+            for (int q = 1; q < nm; ++q) {
+                const ggml_tensor * up = mem[q].mm;
+                if (mul->op == GGML_OP_MUL && ((mul->src[0] == silu && mul->src[1] == up) || (mul->src[1] == silu && mul->src[0] == up)) &&
+                    c.n_uses(up) == 1 && !(up->flags & GGML_TENSOR_FLAG_OUTPUT) && mi_same_shape(up, t) && is_f32(mul) && mi_is_contiguous(mul) &&
+                    up->src[0]->ne[1] == w0->ne[1]) {
+                    act_plan ap; plan_act(c, x, k, 2, mem[q].node, ap);
+                    std::vector<char> skip(c.n, 0);
+                    skip[i] = skip[c.idx(silu)] = skip[mem[q].node] = skip[c.idx(mul)] = 1;
+                    const int at = i, upto = c.idx(mul);
+                    // the product is written at `at` instead of `upto`: must not alias anything still needed, nor our own inputs
+                    if (write_conflicts(c, mul->data, mi_nbytes(mul), at, upto, skip)) break;
+                    if (overlap(mul->data, mi_nbytes(mul), ap.src.X, (size_t) T * ap.src.xs * 4)) break;
+                    mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = 2; L.swiglu = 1;
+                    member g0 = mem[0], g1 = mem[q]; g0.epi = EPI_F32; g0.out = mul; g0.res = nullptr; g1.epi = EPI_F32; g1.out = mul; g1.res = nullptr;
+                    fill_mat(L.m[0], g0); fill_mat(L.m[1], g1);
+                    L.m[0].o_row = 4; L.m[0].o_tok = mul->nb[1];
+                    mi_mmvq_run(st, w0->type, T, L);
+                    c.done[i] = c.done[c.idx(silu)] = c.done[mem[q].node] = c.done[c.idx(mul)] = 1;
+                    return true;
+                }
+            }
+        }
+    }
+    // ---- generic group: per-member epilogues; hoisted members must be alias-safe
+    act_plan ap; plan_act(c, x, k, nm, mem[nm - 1].node, ap);
+    std::vector<char> skip(c.n, 0);
+    int keep = 0;
+    member sel[3];
+    const ggml_tensor * pos = nullptr; const ggml_tensor * rope0 = nullptr;
+    for (int q = 0; q < nm; ++q) {
+        member m = mem[q];
+        plan_member(c, m);
+        if (m.rope) {     // all ropes of a launch must share positions and parameters
+            if (rope0 && (m.rope->src[1] != rope0->src[1] || memcmp(m.rope->op_params, rope0->op_params, sizeof(int32_t)*11) != 0)) { if (q == 0) {} m.epi = EPI_F32; m.out = m.mm; m.rope = nullptr; m.swallowed.clear(); }
+            else { rope0 = m.rope; pos = m.rope->src[1]; }
+        }
+        if (q > 0) {
+            // hoisting: this member's write moves from its own position (or its CPY's) up to node i
+            std::vector<char> sk = skip; sk[m.node] = 1; for (int s : m.swallowed) sk[s] = 1;
+            const int orig = m.swallowed.empty() ? m.node : std::max(m.node, *std::max_element(m.swallowed.begin(), m.swallowed.end()));
+            const size_t nb = mi_nbytes(m.out);
+            if (write_conflicts(c, m.out->data, nb, i, orig, sk)) continue;           // leave it to run at its own position
+            if (overlap(m.out->data, nb, ap.src.X, (size_t) T * ap.src.xs * 4)) continue;
+        }
+        skip[m.node] = 1; for (int s : m.swallowed) skip[s] = 1;
+        sel[keep++] = m;
+    }
+    if (keep == 0) return false;
+    mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = keep; L.swiglu = 0;
+    for (int q = 0; q < keep; ++q) fill_mat(L.m[q], sel[q]);
+    if (rope0) {
+        L.rope.pos = (const int32_t *) pos->data; L.rope.head_dim = (int) rope0->ne[0];
+        L.rope.theta_scale = powf(mi_op_f32(rope0, 5), -2.0f / mi_op_i32(rope0, 1));
+        L.rope.freq_scale = mi_op_f32(rope0, 6); L.rope.attn_factor = mi_op_f32(rope0, 8);
+    }
+    mi_mmvq_run(st, w0->type, T, L);
+    for (int q = 0; q < keep; ++q) { c.done[sel[q].node] = 1; for (int s : sel[q].swallowed) c.done[s] = 1; }
+    return true;
+}
+
+// ---- attention:  kq = MUL_MAT(k, q) ; p = SOFT_MAX(kq, mask, scale) ; kqv = MUL_MAT(v, p) ; PERMUTE ; CONT
+static bool run_attention(mi_backend_ctx * ctx, gctx & c, int i) {
+    const ggml_tensor * kq = c.g->nodes[i];
+    const ggml_tensor * k = kq->src[0], * q = kq->src[1];
+    if (k->type != GGML_TYPE_F16 || !is_f32(q) || k->nb[0] != 2 || q->nb[0] != 4 || k->ne[3] != 1 || q->ne[3] != 1) return false;
+    if (c.n_uses(kq) != 1 || (kq->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    const ggml_tensor * sm = c.g->nodes[c.last_use(kq)];
+    if (sm->op != GGML_OP_SOFT_MAX || sm->src[0] != kq || mi_op_f32(sm, 1) != 0.0f || c.n_uses(sm) != 1 || (sm->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    const ggml_tensor * mask = sm->src[1];
+    if (mask && !((mask->type == GGML_TYPE_F32 || mask->type == GGML_TYPE_F16) && mi_is_contiguous(mask) && mask->ne[0] == kq->ne[0] && mask->ne[1] >= kq->ne[1])) return false;
+    const ggml_tensor * kqv = c.g->nodes[c.last_use(sm)];
+    if (kqv->op != GGML_OP_MUL_MAT || kqv->src[1] != sm || c.n_uses(kqv) != 1 || (kqv->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    const ggml_tensor * v = kqv->src[0];
+    if (v->type != GGML_TYPE_F16 || v->nb[0] != 2 || v->ne[3] != 1 || v->ne[0] != k->ne[1] || v->ne[1] != k->ne[0] || v->ne[2] != k->ne[2]) return false;
+    const ggml_tensor * pm = c.g->nodes[c.last_use(kqv)];
+    if (pm->op != GGML_OP_PERMUTE || pm->src[0] != kqv || c.n_uses(pm) != 1) return false;
+    if (!(mi_op_i32(pm, 0) == 0 && mi_op_i32(pm, 1) == 2 && mi_op_i32(pm, 2) == 1 && mi_op_i32(pm, 3) == 3)) return false;
+    const ggml_tensor * ct = c.g->nodes[c.last_use(pm)];
+    if (ct->op != GGML_OP_CONT || ct->src[0] != pm || !is_f32(ct) || !mi_is_contiguous(ct)) return false;
+    mi_attn_args a{};
+    a.d = (int) k->ne[0]; a.n_kv = (int) k->ne[1]; a.H_kv = (int) k->ne[2]; a.T = (int) q->ne[1]; a.H = (int) q->ne[2];
+    if (kq->ne[0] != a.n_kv || kq->ne[1] != a.T || kq->ne[2] != a.H || mi_nelements(ct) != (int64_t) a.d * a.H * a.T) return false;
+    a.q = q->data; a.q_nb1 = q->nb[1]; a.q_nb2 = q->nb[2];
+    a.k = k->data; a.k_nb1 = k->nb[1]; a.k_nb2 = k->nb[2];
+    a.v = v->data; a.v_nb1 = v->nb[1]; a.v_nb2 = v->nb[2];
+    a.mask = mask ? mask->data : nullptr; a.mask_f16 = mask && mask->type == GGML_TYPE_F16; a.mask_nb1 = mask ? mask->nb[1] : 0;
+    a.out = (float *) ct->data; a.o_nb1 = (int64_t) a.d * 4; a.o_nb2 = (int64_t) a.d * a.H * 4;
+    a.scale = mi_op_f32(sm, 0);
+    if (!mi_attn_small_supported(a)) return false;
+    // the result lands at node i instead of at CONT's position
+    std::vector<char> skip(c.n, 0);
+    const int ism = c.idx(sm), ikqv = c.idx(kqv), ipm = c.idx(pm), ict = c.idx(ct);
+    skip[i] = skip[ism] = skip[ikqv] = skip[ipm] = skip[ict] = 1;
+    if (write_conflicts(c, ct->data, mi_nbytes(ct), i, ict, skip)) return false;
+    if (overlap(ct->data, mi_nbytes(ct), q->data, mi_nbytes(q))) return false;
+    mi_op_attn_small(ctx->stream, a);
+    c.done[i] = c.done[ism] = c.done[ikqv] = c.done[ipm] = c.done[ict] = 1;
+    return true;
+}
 
 enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
-    const int n = g->n_nodes;
-    use_map uses((size_t) n * 3 + 16);
-    for (int i = 0; i < n; ++i) {
-        const ggml_tensor * t = g->nodes[i];
-        for (int s = 0; s < GGML_MAX_SRC; ++s) if (t->src[s]) uses.add(t->src[s]);
-    }
+    gctx c(g);
+    const int n = c.n;
     hipStream_t st = ctx->stream;
     static const bool no_fuse = getenv("GGML_MI355X_NO_FUSION") != nullptr;
+    const bool fuse = !no_fuse;
 
     for (int i = 0; i < n; ++i) {
         ggml_tensor * t = g->nodes[i];
-        if (is_view_op(t->op) || mi_nelements(t) == 0) continue;
+        if (c.done[i] || is_view_op(t->op) || mi_nelements(t) == 0) continue;
         ggml_tensor * nx = (i + 1 < n) ? g->nodes[i + 1] : nullptr;
-        const bool single_use = !no_fuse && uses.get(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
+        const bool single_use = fuse && c.n_uses(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
 
         switch (t->op) {
             case GGML_OP_RMS_NORM: {
-                // RMS_NORM -> MUL(norm, weight[ne0]) : llm_build_norm, R/src/llama.cpp:329-365
+                if (fuse && can_defer_norm(c, i)) {                   // folded into the prologue of the mat-vecs that read it
+                    c.done[i] = 2;
+                    if (c.n_uses(t) == 1 && nx && nx->op == GGML_OP_MUL && nx->src[0] == t) c.done[i + 1] = 2;
+                    break;
+                }
                 if (single_use && nx && nx->op == GGML_OP_MUL && nx->src[0] == t && is_f32(nx->src[1]) && is_f32(nx) &&
                     nx->src[1]->ne[0] == t->ne[0] && mi_nrows(nx->src[1]) == 1 && nx->src[1]->nb[0] == 4 && nx->nb[0] == 4 && mi_same_shape(nx, t)) {
-                    mi_op_rms_norm(st, t, nx->src[1], nx); ++i;
+                    mi_op_rms_norm(st, t, nx->src[1], nx); c.done[i + 1] = 1;
                 } else {
                     mi_op_rms_norm(st, t, nullptr, t);
                 }
             } break;
             case GGML_OP_MUL_MAT: {
                 if (mi_mul_mat_q_supported_type(t->src[0]->type)) {
-                    // MUL_MAT -> ADD(residual): attention output / ffn_down + inpSA (R/src/llama.cpp:1770,1800)
-                    const ggml_tensor * res = nullptr;
-                    if (single_use && nx && nx->op == GGML_OP_ADD && is_f32(nx) && nx->nb[0] == 4 && mi_same_shape(nx, t)) {
-                        if      (nx->src[0] == t && is_f32(nx->src[1]) && mi_same_shape(nx->src[1], t) && nx->src[1]->nb[0] == 4) res = nx->src[1];
-                        else if (nx->src[1] == t && is_f32(nx->src[0]) && mi_same_shape(nx->src[0], t) && nx->src[0]->nb[0] == 4) res = nx->src[0];
-                    }
-                    if (res) { mi_op_mul_mat_q(st, t, res, nx); ++i; }
-                    else     { mi_op_mul_mat_q(st, t, nullptr, t); }
+                    if (!run_mmvq_group(ctx, c, i, fuse)) mi_op_mul_mat_q(st, t, nullptr, t);
                 } else {
-                    int consumed = 0;
-                    if (!no_fuse && try_fuse_attention(ctx, g, i, uses, &consumed)) { i += consumed; break; }
+                    if (fuse && run_attention(ctx, c, i)) break;
                     mi_op_mul_mat_f(st, t);
                 }
             } break;
             case GGML_OP_UNARY: {
-                // SILU(gate) -> MUL(silu, up): llm_build_ffn SwiGLU, R/src/llama.cpp:456-600
                 if (single_use && mi_op_i32(t, 0) == GGML_UNARY_OP_SILU && nx && nx->op == GGML_OP_MUL && is_f32(nx) && mi_is_contiguous(nx) && mi_same_shape(nx, t)) {
                     const ggml_tensor * other = nx->src[0] == t ? nx->src[1] : (nx->src[1] == t ? nx->src[0] : nullptr);
-                    if (other && is_f32(other) && mi_is_contiguous(other) && mi_same_shape(other, t)) { mi_op_silu_mul(st, t->src[0], other, nx); ++i; break; }
+                    if (other && is_f32(other) && mi_is_contiguous(other) && mi_same_shape(other, t)) { mi_op_silu_mul(st, t->src[0], other, nx); c.done[i + 1] = 1; break; }
                 }
                 mi_op_unary(st, t);
             } break;
@@ -150,11 +443,4 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { MI_LOG("graph_compute: launch error: %s", hipGetErrorString(e)); return GGML_STATUS_FAILED; }
     return GGML_STATUS_SUCCESS;
-}
-
-// ---- attention:  kq = MUL_MAT(k, q) ; p = SOFT_MAX(kq, mask, scale) ; kqv = MUL_MAT(v, p) ; [PERMUTE ; CONT]
-// as built by llm_build_kqv without flash-attention (R/src/llama.cpp:706-828).
-static bool try_fuse_attention(mi_backend_ctx * ctx, ggml_cgraph * g, int i, const use_map & uses, int * consumed) {
-    (void) ctx; (void) g; (void) i; (void) uses; (void) consumed;
-    return false;   // enabled in kernels_attn.hip once parity-tested
 }

@@ -18,6 +18,19 @@ void mi_op_soft_max (hipStream_t st, const ggml_tensor * dst);
 void mi_op_silu_mul (hipStream_t st, const ggml_tensor * gate, const ggml_tensor * up, const ggml_tensor * dst);
 
 // ---- matrix products (kernels_mmvq.hip / kernels_mmf.hip) ----
+enum { EPI_F32 = 0, EPI_ROPE_F32 = 1, EPI_ROPE_F16 = 2, EPI_F16 = 3 };
+struct act_src {                        // activations of a mat-vec launch (see kernels_mmvq.hip)
+    const float * X; int64_t xs; const float * norm_w; int norm; float eps;
+};
+struct mmvq_mat {
+    const char * W; int64_t row_bytes; int rows; int epi;
+    char * out; int64_t o_row, o_tok;   // element (row, token) is written at out + row*o_row + token*o_tok  (bytes)
+    const float * res; int64_t r_tok;   // optional residual (EPI_F32): res[token*r_tok + row]
+};
+struct mmvq_rope { const int32_t * pos; int head_dim; float theta_scale, freq_scale, attn_factor; };
+struct mmvq_launch { act_src act; int k; int n_mat; int swiglu; mmvq_mat m[3]; mmvq_rope rope; };
+int  mi_mmvq_max_tokens(int type, int k);
+void mi_mmvq_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L);
 // quantised weight x f32 activations; residual (nullable) is added in the epilogue (fused ADD)
 void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out);
 // f16 / f32 / bf16 src0 x f32 src1 (attention K.q, V.p and unquantised weights)
@@ -35,3 +48,4 @@ struct mi_attn_args {
     float scale;
 };
 void mi_op_attn_small(hipStream_t st, const mi_attn_args & a);
+bool mi_attn_small_supported(const mi_attn_args & a);

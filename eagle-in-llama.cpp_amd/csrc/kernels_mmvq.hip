@@ -59,82 +59,107 @@ static inline size_t act_lds_bytes(bool ktype, int T, int k) {
     return ktype ? (size_t) T*k + (size_t) T*(k/256)*4 + (size_t) T*(k/16)*2 : (size_t) T*k + (size_t) T*(k/32)*4;
 }
 
-// ---------------------------------------------------------------- prologue: quantise X[T][k] into LDS
-// Q8_K rule: the scale comes from the FIRST element of largest magnitude, iscale = -127/max,
-// q = min(127, rne(iscale*x)), d = 1/iscale, bsums over groups of 16.
-template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const float * __restrict__ X, int64_t xs, int k, int8_t * q, float * d, short * bs) {
+// ---------------------------------------------------------------- prologue: (rms_norm * w) -> quantise X[T][k] into LDS
+// Activation source of a launch.  With `norm` the block first recomputes RMS_NORM (+ MUL by the norm weight) of
+// every token row itself -- sum of squares in double exactly like ggml_compute_forward_rms_norm_f32 -- so the
+// normalised fp32 tensor never goes to HBM and the separate norm launch disappears.
+template <int T, int NW> __device__ __forceinline__ void row_scales(const act_src & a, int k, float * sc /*LDS [T]*/, double * red /*LDS [NW]*/) {
     const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
-    const int nsb = k / 256;
-    for (int u = wave; u < T*nsb; u += NW) {
-        const int t = u / nsb, sb = u - t*nsb;
-        const float4 v = *(const float4 *)(X + t*xs + sb*256 + lane*4);
-        const float xv[4] = { v.x, v.y, v.z, v.w };
-        float amax = 0.0f; int first = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float ax = fabsf(xv[j]); if (ax > amax) { amax = ax; first = j; } }
-        float wmax = amax;
-#pragma unroll
-        for (int o = WAVE/2; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, WAVE));
-        int key = (amax == wmax) ? (lane*4 + first) : (1 << 20);      // lowest index holding the maximum
-#pragma unroll
-        for (int o = WAVE/2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o, WAVE));
-        const float cand = (first == 0) ? xv[0] : (first == 1) ? xv[1] : (first == 2) ? xv[2] : xv[3];
-        const float mx = __shfl(cand, (key >> 2) & 63, WAVE);
-        int   packed = 0; int s = 0; float dd = 0.0f;
-        if (wmax != 0.0f) {
-            const float iscale = -127.f / mx;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int qi = __float2int_rn(iscale * xv[j]);
-                qi = min(127, qi);
-                s += qi;
-                packed |= (qi & 0xff) << (8*j);
-            }
-            dd = 1.0f / iscale;
+    for (int t = 0; t < T; ++t) {
+        double s = 0.0;
+        for (int i = threadIdx.x*4; i < k; i += NW*WAVE*4) {
+            const float4 v = *(const float4 *)(a.X + t*a.xs + i);
+            s += (double)(v.x*v.x); s += (double)(v.y*v.y); s += (double)(v.z*v.z); s += (double)(v.w*v.w);
         }
-        *(int *)(q + (size_t) t*k + sb*256 + lane*4) = packed;
-        s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE);
-        if ((lane & 3) == 0) bs[(size_t) t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
-        if (lane == 0) d[t*nsb + sb] = dd;
+#pragma unroll
+        for (int o = WAVE/2; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) { double tot = 0.0; for (int w = 0; w < NW; ++w) tot += red[w]; const float mean = (float)(tot / (double) k); sc[t] = 1.0f / sqrtf(mean + a.eps); }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ float4 fetch4(const act_src & a, const float * sc, int t, int e) {
+    float4 v = *(const float4 *)(a.X + t*a.xs + e);
+    if (a.norm) {
+        const float s = sc[t];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        if (a.norm_w) { const float4 w = *(const float4 *)(a.norm_w + e); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+    }
+    return v;
+}
+// Q8_K rule: the scale comes from the FIRST element of largest magnitude, iscale = -127/max,
+// q = min(127, rne(iscale*x)), d = 1/iscale, bsums over groups of 16.  One wave = one 256-element super-block;
+// loads for PB super-blocks are issued before the first reduction so their latencies overlap.
+template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, short * bs) {
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    const int nsb = k / 256, nu = T*nsb;
+    constexpr int PB = 4;
+    for (int u0 = wave; u0 < nu; u0 += NW*PB) {
+        float4 vv[PB];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) { const int u = u0 + p*NW; if (u < nu) { const int t = u / nsb, sb = u - t*nsb; vv[p] = fetch4(a, sc, t, sb*256 + lane*4); } }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int u = u0 + p*NW;
+            if (u >= nu) break;
+            const int t = u / nsb, sb = u - t*nsb;
+            const float xv[4] = { vv[p].x, vv[p].y, vv[p].z, vv[p].w };
+            float amax = 0.0f; int first = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float ax = fabsf(xv[j]); if (ax > amax) { amax = ax; first = j; } }
+            float wmax = amax;
+#pragma unroll
+            for (int o = WAVE/2; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, WAVE));
+            int key = (amax == wmax) ? (lane*4 + first) : (1 << 20);      // lowest index holding the maximum
+#pragma unroll
+            for (int o = WAVE/2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o, WAVE));
+            const float cand = (first == 0) ? xv[0] : (first == 1) ? xv[1] : (first == 2) ? xv[2] : xv[3];
+            const float mx = __shfl(cand, (key >> 2) & 63, WAVE);
+            int packed = 0; int s = 0; float dd = 0.0f;
+            if (wmax != 0.0f) {
+                const float iscale = -127.f / mx;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { int qi = __float2int_rn(iscale * xv[j]); qi = min(127, qi); s += qi; packed |= (qi & 0xff) << (8*j); }
+                dd = 1.0f / iscale;
+            }
+            *(int *)(q + (size_t) t*k + sb*256 + lane*4) = packed;
+            s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE);
+            if ((lane & 3) == 0) bs[(size_t) t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
+            if (lane == 0) d[t*nsb + sb] = dd;
+        }
     }
 }
 // Q8_0 rule: d = amax/127, id = 1/d, q = roundf(x*id) (half away from zero), d stored through fp16.
-template <int T, int NW> __device__ __forceinline__ void quant_q80_to_lds(const float * __restrict__ X, int64_t xs, int k, int8_t * q, float * d) {
+__device__ __forceinline__ void q80_unit(const float4 v, int8_t * qdst, float * ddst, int lane, bool write) {
+    const float xv[4] = { v.x, v.y, v.z, v.w };
+    float amax = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 2, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 4, WAVE));
+    const float dd = amax / 127.f;
+    const float id = dd ? 1.0f/dd : 0.0f;
+    int packed = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int qi = (int) roundf(xv[j]*id); packed |= (qi & 0xff) << (8*j); }
+    if (write) { *(int *) qdst = packed; if ((lane & 7) == 0) *ddst = __half2float(__float2half_rn(dd)); }
+}
+template <int T, int NW> __device__ __forceinline__ void quant_q80_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d) {
     const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
-    const int nch = k / 256;                       // full 256-element chunks (8 blocks of 32) per wave pass
-    const int nb  = k / 32;
-    for (int u = wave; u < T*nch; u += NW) {
-        const int t = u / nch, ch = u - t*nch;
-        const float4 v = *(const float4 *)(X + t*xs + ch*256 + lane*4);
-        const float xv[4] = { v.x, v.y, v.z, v.w };
-        float amax = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
-        amax = fmaxf(amax, __shfl_xor(amax, 1, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 2, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 4, WAVE));
-        const float dd = amax / 127.f;
-        const float id = dd ? 1.0f/dd : 0.0f;
-        int packed = 0;
+    const int nch = (k + 255) / 256, nb = k / 32, nu = T*nch;       // a chunk = 256 elements = 8 blocks of 32 (last one may be ragged)
+    constexpr int PB = 4;
+    for (int u0 = wave; u0 < nu; u0 += NW*PB) {
+        float4 vv[PB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int qi = (int) roundf(xv[j]*id); packed |= (qi & 0xff) << (8*j); }
-        *(int *)(q + (size_t) t*k + ch*256 + lane*4) = packed;
-        if ((lane & 7) == 0) d[t*nb + ch*8 + (lane >> 3)] = __half2float(__float2half_rn(dd));
-    }
-    // ragged tail (k % 256 != 0): blocks of 32 handled by 8-lane groups of wave 0
-    const int tail0 = nch * 256;
-    if (tail0 < k && wave == 0) {
-        for (int t = 0; t < T; ++t) {
-            const int e = tail0 + lane*4;
-            float xv[4] = {0, 0, 0, 0};
-            if (e < k) { const float4 v = *(const float4 *)(X + t*xs + e); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
-            float amax = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
-            amax = fmaxf(amax, __shfl_xor(amax, 1, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 2, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 4, WAVE));
-            const float dd = amax / 127.f;
-            const float id = dd ? 1.0f/dd : 0.0f;
-            int packed = 0;
+        for (int p = 0; p < PB; ++p) {
+            const int u = u0 + p*NW; vv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < nu) { const int t = u / nch, ch = u - t*nch, e = ch*256 + lane*4; if (e < k) vv[p] = fetch4(a, sc, t, e); }
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int qi = (int) roundf(xv[j]*id); packed |= (qi & 0xff) << (8*j); }
-            if (e < k) {
-                *(int *)(q + (size_t) t*k + e) = packed;
-                if ((lane & 7) == 0) d[t*nb + e/32] = __half2float(__float2half_rn(dd));
-            }
+        for (int p = 0; p < PB; ++p) {
+            const int u = u0 + p*NW;
+            if (u >= nu) break;
+            const int t = u / nch, ch = u - t*nch, e = ch*256 + lane*4;
+            q80_unit(vv[p], q + (size_t) t*k + e, d + t*nb + e/32, lane, e < k);
         }
     }
 }
@@ -300,57 +325,139 @@ template <> struct wfrag<GGML_TYPE_Q4_0> {
 };
 
 // ---------------------------------------------------------------- the kernel
-constexpr int MMVQ_R = 2;   // weight rows per wave per pass
+// One launch = up to three weight matrices of ONE quant type sharing the same activations (wq|wk|wv, or gate|up),
+// each with its own epilogue:
+//   EPI_F32       dst f32 (+ residual row: fused GGML_OP_ADD)
+//   EPI_ROPE_F32  RoPE (mode NORM) on row pairs, f32 out                      (Qcur)
+//   EPI_ROPE_F16  RoPE, then f16 store straight into the K cache view          (Kcur -> cpy -> k_cache_view)
+//   EPI_F16       f16 store with row/token strides: the transposed V cache     (Vcur -> transpose -> cpy)
+// DUAL: matrices 0/1 are ffn_gate/ffn_up, a wave computes the same rows of both and writes silu(g)*u (SwiGLU).
+constexpr int MMVQ_R = 2;   // weight rows per wave per pass (RoPE pairs live in one wave)
 
-template <int TYPE, int T, int NW>
-__global__ void __launch_bounds__(NW*WAVE) k_mmvq(const char * __restrict__ W, int64_t w_row_bytes,
-                                                  const float * __restrict__ X, int64_t x_stride,
-                                                  float * __restrict__ D, int64_t d_stride,
-                                                  const float * __restrict__ RES, int64_t res_stride,
-                                                  int k, int rows) {
+template <int TYPE, int T, bool DUAL> struct acc_t { float g[MMVQ_R][T]; float u[DUAL ? MMVQ_R : 1][DUAL ? T : 1]; };
+
+template <int TYPE, int T, int NW, bool DUAL>
+__global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using WT = wt<TYPE>;
+    const int k = L.k;
     int8_t * lq = (int8_t *) smem;
     float  * ld = (float *)(smem + (size_t) T*k);
-    short  * lb = (short *)(smem + (size_t) T*k + (size_t) T*(k/256)*4);
-    if (WT::K) quant_q8K_to_lds<T, NW>(X, x_stride, k, lq, ld, lb);
-    else       quant_q80_to_lds<T, NW>(X, x_stride, k, lq, ld);
-    __syncthreads();
-    act_lds a; a.q = lq; a.d = ld; a.bs = lb; a.k = k;
+    short  * lb = (short *)((char *) ld + (size_t) T*(WT::K ? k/256 : k/32)*4);
+    char   * tail = (char *) lb + (WT::K ? (size_t) T*(k/16)*2 : 0);
+    tail = (char *)(((uintptr_t) tail + 7) & ~(uintptr_t) 7);
+    double * red = (double *) tail;
+    float  * sc  = (float *)(tail + NW*8);
 
     const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
     const int nsteps = (k + WT::STEP - 1) / WT::STEP;
-    for (int row0 = (blockIdx.x*NW + wave)*MMVQ_R; row0 < rows; row0 += gridDim.x*NW*MMVQ_R) {
-        float acc[MMVQ_R][T];
-#pragma unroll
-        for (int r = 0; r < MMVQ_R; ++r)
-#pragma unroll
-            for (int t = 0; t < T; ++t) acc[r][t] = 0.f;
-        const char * rp[MMVQ_R];
-#pragma unroll
-        for (int r = 0; r < MMVQ_R; ++r) rp[r] = W + (size_t) min(row0 + r, rows - 1) * w_row_bytes;
+    // group -> (matrix, first row)
+    const int c0 = (L.m[0].rows + MMVQ_R - 1) / MMVQ_R;
+    const int c1 = (!DUAL && L.n_mat > 1) ? (L.m[1].rows + MMVQ_R - 1) / MMVQ_R : 0;
+    const int c2 = (!DUAL && L.n_mat > 2) ? (L.m[2].rows + MMVQ_R - 1) / MMVQ_R : 0;
+    const int total = c0 + c1 + c2;
+    auto locate = [&](int g, int & mi, int & row0) { if (g < c0) { mi = 0; row0 = g*MMVQ_R; } else if (g < c0 + c1) { mi = 1; row0 = (g - c0)*MMVQ_R; } else { mi = 2; row0 = (g - c0 - c1)*MMVQ_R; } };
 
-        for (int s = 0; s < nsteps; s += 2) {
-            wfrag<TYPE> f[2][MMVQ_R];
+    // issue the first weight loads BEFORE the activation prologue: their HBM latency hides behind it
+    wfrag<TYPE> f[2][MMVQ_R], fu[DUAL ? 2 : 1][DUAL ? MMVQ_R : 1];
+    int g = blockIdx.x*NW + wave;
+    if (g < total) {
+        int mi, row0; locate(g, mi, row0);
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < MMVQ_R; ++r) f[u][r].load(rp[r], s + u, lane, (s + u < nsteps) ? k : 0);
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < MMVQ_R; ++r) f[u][r].template dot<T>(a, s + u, lane, acc[r]);
-        }
+            for (int r = 0; r < MMVQ_R; ++r) {
+                f[u][r].load(L.m[mi].W + (size_t) min(row0 + r, L.m[mi].rows - 1) * L.m[mi].row_bytes, u, lane, (u < nsteps) ? k : 0);
+                if (DUAL) fu[u][r].load(L.m[1].W + (size_t) min(row0 + r, L.m[1].rows - 1) * L.m[1].row_bytes, u, lane, (u < nsteps) ? k : 0);
+            }
+    }
+    if (L.act.norm) row_scales<T, NW>(L.act, k, sc, red);
+    if (WT::K) quant_q8K_to_lds<T, NW>(L.act, sc, k, lq, ld, lb);
+    else       quant_q80_to_lds<T, NW>(L.act, sc, k, lq, ld);
+    __syncthreads();
+    act_lds a; a.q = lq; a.d = ld; a.bs = lb; a.k = k;
+
+    bool first = true;
+    for (; g < total; g += gridDim.x*NW, first = false) {
+        int mi, row0; locate(g, mi, row0);
+        const mmvq_mat & M = L.m[mi];
+        float acc[MMVQ_R][T], accu[DUAL ? MMVQ_R : 1][DUAL ? T : 1];
 #pragma unroll
         for (int r = 0; r < MMVQ_R; ++r)
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const float v = wave_sum_f(acc[r][t]);
-                if (lane == 0 && row0 + r < rows) {
-                    const int64_t row = row0 + r;
-                    D[t*d_stride + row] = RES ? v + RES[t*res_stride + row] : v;
+            for (int t = 0; t < T; ++t) { acc[r][t] = 0.f; if (DUAL) accu[r][t] = 0.f; }
+        const char * rp[MMVQ_R], * rpu[MMVQ_R];
+#pragma unroll
+        for (int r = 0; r < MMVQ_R; ++r) {
+            rp[r] = M.W + (size_t) min(row0 + r, M.rows - 1) * M.row_bytes;
+            rpu[r] = DUAL ? L.m[1].W + (size_t) min(row0 + r, L.m[1].rows - 1) * L.m[1].row_bytes : nullptr;
+        }
+        for (int s = 0; s < nsteps; s += 2) {
+            if (!(first && s == 0)) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < MMVQ_R; ++r) {
+                        f[u][r].load(rp[r], s + u, lane, (s + u < nsteps) ? k : 0);
+                        if (DUAL) fu[u][r].load(rpu[r], s + u, lane, (s + u < nsteps) ? k : 0);
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < MMVQ_R; ++r) {
+                    f[u][r].template dot<T>(a, s + u, lane, acc[r]);
+                    if (DUAL) fu[u][r].template dot<T>(a, s + u, lane, accu[r]);
+                }
+        }
+        // ---- reduce: every lane ends up with every sum
+#pragma unroll
+        for (int r = 0; r < MMVQ_R; ++r)
+#pragma unroll
+            for (int t = 0; t < T; ++t) { acc[r][t] = wave_sum_f(acc[r][t]); if (DUAL) accu[r][t] = wave_sum_f(accu[r][t]); }
+        // ---- epilogue: lane t finishes token t
+        const bool ok1 = row0 + 1 < M.rows;
+        if (DUAL) {
+            float * out = (float *) L.m[0].out;
+#pragma unroll
+            for (int t = 0; t < T; ++t) if (lane == t) {
+                const float g0 = acc[0][t], g1 = acc[1][t];
+                *(float *)((char *) out + (size_t) row0*L.m[0].o_row + (size_t) t*L.m[0].o_tok) = (g0 / (1.0f + expf(-g0))) * accu[0][t];
+                if (ok1) *(float *)((char *) out + (size_t)(row0 + 1)*L.m[0].o_row + (size_t) t*L.m[0].o_tok) = (g1 / (1.0f + expf(-g1))) * accu[1][t];
+            }
+        } else if (M.epi == EPI_F32) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) if (lane == t) {
+                float v0 = acc[0][t], v1 = acc[1][t];
+                if (M.res) { v0 += M.res[(size_t) t*M.r_tok + row0]; if (ok1) v1 += M.res[(size_t) t*M.r_tok + row0 + 1]; }
+                *(float *)(M.out + (size_t) row0*M.o_row + (size_t) t*M.o_tok) = v0;
+                if (ok1) *(float *)(M.out + (size_t)(row0 + 1)*M.o_row + (size_t) t*M.o_tok) = v1;
+            }
+        } else if (M.epi == EPI_F16) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) if (lane == t) {
+                *(__half *)(M.out + (size_t) row0*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(acc[0][t]);
+                if (ok1) *(__half *)(M.out + (size_t)(row0 + 1)*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(acc[1][t]);
+            }
+        } else {   // RoPE on the pair (row0, row0+1): theta by the reference's float recurrence (ggml_rope_cache_init)
+            const int ip = (row0 % L.rope.head_dim) >> 1;
+#pragma unroll
+            for (int t = 0; t < T; ++t) if (lane == t) {
+                float theta = (float) L.rope.pos[t];
+                for (int j = 0; j < ip; ++j) theta *= L.rope.theta_scale;
+                const float th = L.rope.freq_scale * theta;
+                const float c = cosf(th) * L.rope.attn_factor, sn = sinf(th) * L.rope.attn_factor;
+                const float x0 = acc[0][t], x1 = acc[1][t];
+                const float y0 = x0*c - x1*sn, y1 = x0*sn + x1*c;
+                if (M.epi == EPI_ROPE_F32) {
+                    *(float *)(M.out + (size_t) row0*M.o_row + (size_t) t*M.o_tok) = y0;
+                    *(float *)(M.out + (size_t)(row0 + 1)*M.o_row + (size_t) t*M.o_tok) = y1;
+                } else {
+                    *(__half *)(M.out + (size_t) row0*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(y0);
+                    *(__half *)(M.out + (size_t)(row0 + 1)*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(y1);
                 }
             }
+        }
     }
 }
 
@@ -364,52 +471,72 @@ static void ensure_lds_attr(const void * fn, size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
     g_attr_done.insert(fn);
 }
+static inline size_t lds_total(bool ktype, int T, int k, int NW) { return act_lds_bytes(ktype, T, k) + 8 + (size_t) NW*8 + (size_t) T*4 + 16; }
 
-template <int TYPE, int T, int NW>
-static void launch_one(hipStream_t st, const char * W, int64_t wrb, const float * X, int64_t xs, float * D, int64_t ds,
-                       const float * RES, int64_t rs, int k, int rows) {
-    const size_t lds = act_lds_bytes(wt<TYPE>::K, T, k);
+template <int TYPE, int T, int NW, bool DUAL>
+static void launch_one(hipStream_t st, const mmvq_launch & L) {
+    const size_t lds = lds_total(wt<TYPE>::K, T, L.k, NW);
     MI_ASSERT(lds <= 160*1024);
-    const int per_block = NW * MMVQ_R;
-    int max_blocks_cu = (int) ((160*1024) / (lds + 1024));
+    int total = 0;
+    if (DUAL) total = (L.m[0].rows + MMVQ_R - 1) / MMVQ_R;
+    else for (int i = 0; i < L.n_mat; ++i) total += (L.m[i].rows + MMVQ_R - 1) / MMVQ_R;
+    int max_blocks_cu = (int) ((160*1024) / (lds + 512));
     if (max_blocks_cu < 1) max_blocks_cu = 1;
-    const int cap_waves = 32 / NW;                                   // 32 waves per CU
+    const int cap_waves = 32 / NW;
     if (max_blocks_cu > cap_waves) max_blocks_cu = cap_waves;
     if (max_blocks_cu > 4) max_blocks_cu = 4;
-    int grid = (rows + per_block - 1) / per_block;
+    int grid = (total + NW - 1) / NW;
     const int cap = 256 * max_blocks_cu;
     if (grid > cap) grid = cap;
-    auto fn = k_mmvq<TYPE, T, NW>;
+    if (grid < 1) return;
+    auto fn = k_mmvq<TYPE, T, NW, DUAL>;
     ensure_lds_attr((const void *) fn, lds);
-    fn<<<grid, NW*WAVE, lds, st>>>(W, wrb, X, xs, D, ds, RES, rs, k, rows);
+    fn<<<grid, NW*WAVE, lds, st>>>(L);
 }
-
-template <int TYPE, int T>
-static void launch_T(hipStream_t st, const char * W, int64_t wrb, const float * X, int64_t xs, float * D, int64_t ds,
-                     const float * RES, int64_t rs, int k, int rows) {
-    const size_t lds = act_lds_bytes(wt<TYPE>::K, T, k);
-    if (lds > 36*1024) launch_one<TYPE, T, 8>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows);
-    else               launch_one<TYPE, T, 4 >(st, W, wrb, X, xs, D, ds, RES, rs, k, rows);
+template <int TYPE, int T> static void launch_T(hipStream_t st, const mmvq_launch & L) {
+    const size_t lds = act_lds_bytes(wt<TYPE>::K, T, L.k);
+    if (L.swiglu) { if (lds > 36*1024) launch_one<TYPE, T, 8, true >(st, L); else launch_one<TYPE, T, 4, true >(st, L); }
+    else          { if (lds > 36*1024) launch_one<TYPE, T, 8, false>(st, L); else launch_one<TYPE, T, 4, false>(st, L); }
 }
-
-template <int TYPE>
-static void launch_type(hipStream_t st, int T, const char * W, int64_t wrb, const float * X, int64_t xs, float * D, int64_t ds,
-                        const float * RES, int64_t rs, int k, int rows) {
+template <int TYPE> static void launch_type(hipStream_t st, int T, const mmvq_launch & L) {
     switch (T) {
-        case 1: launch_T<TYPE, 1>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
-        case 2: launch_T<TYPE, 2>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
-        case 3: launch_T<TYPE, 3>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
-        case 4: launch_T<TYPE, 4>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
-        case 5: launch_T<TYPE, 5>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
-        case 6: launch_T<TYPE, 6>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
-        case 7: launch_T<TYPE, 7>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
-        case 8: launch_T<TYPE, 8>(st, W, wrb, X, xs, D, ds, RES, rs, k, rows); break;
+        case 1: launch_T<TYPE, 1>(st, L); break; case 2: launch_T<TYPE, 2>(st, L); break;
+        case 3: launch_T<TYPE, 3>(st, L); break; case 4: launch_T<TYPE, 4>(st, L); break;
+        case 5: launch_T<TYPE, 5>(st, L); break; case 6: launch_T<TYPE, 6>(st, L); break;
+        case 7: launch_T<TYPE, 7>(st, L); break; case 8: launch_T<TYPE, 8>(st, L); break;
         default: MI_ABORT("mmvq: T=%d", T);
     }
 }
 
 bool mi_mul_mat_q_supported_type(int type) {
     return type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K || type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q4_0;
+}
+
+int mi_mmvq_max_tokens(int type, int k) {
+    const size_t per_tok = act_lds_bytes(mi_traits(type).blck == 256, 1, k);
+    int tmax = (int) ((150*1024) / per_tok);
+    return tmax > 8 ? 8 : tmax;
+}
+
+// Runs one (possibly multi-matrix) product over Ttot tokens, at most mi_mmvq_max_tokens() per launch.
+void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0) {
+    const int tmax = mi_mmvq_max_tokens(type, L0.k);
+    MI_ASSERT(tmax >= 1);
+    for (int t0 = 0; t0 < Ttot; t0 += tmax) {
+        const int T = (Ttot - t0) < tmax ? (Ttot - t0) : tmax;
+        mmvq_launch L = L0;
+        L.act.X += (size_t) t0 * L.act.xs;
+        for (int i = 0; i < L.n_mat; ++i) { L.m[i].out += (size_t) t0 * L.m[i].o_tok; if (L.m[i].res) L.m[i].res += (size_t) t0 * L.m[i].r_tok; }
+        if (L.rope.pos) L.rope.pos += t0;
+        switch (type) {
+            case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, T, L); break;
+            case GGML_TYPE_Q5_K: launch_type<GGML_TYPE_Q5_K>(st, T, L); break;
+            case GGML_TYPE_Q6_K: launch_type<GGML_TYPE_Q6_K>(st, T, L); break;
+            case GGML_TYPE_Q8_0: launch_type<GGML_TYPE_Q8_0>(st, T, L); break;
+            case GGML_TYPE_Q4_0: launch_type<GGML_TYPE_Q4_0>(st, T, L); break;
+            default: MI_ABORT("mmvq: unsupported weight type %d", type);
+        }
+    }
 }
 
 // dst[rows, T, b2, b3] = W[k, rows, b2/r2, b3/r3] . X[k, T, b2, b3]   (+ residual)
@@ -420,27 +547,13 @@ void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor 
     if (k == 0 || rows == 0 || Ttot == 0) return;
     MI_ASSERT(x->type == GGML_TYPE_F32 && x->nb[0] == 4 && out->nb[0] == 4);
     const int64_t r2 = x->ne[2] / w->ne[2], r3 = x->ne[3] / w->ne[3];
-    // tokens per launch: as many as fit one CU's LDS (8 at most)
-    const size_t per_tok = act_lds_bytes(mi_traits(w->type).blck == 256, 1, k);
-    int tmax = (int) ((150*1024) / per_tok);
-    if (tmax > 8) tmax = 8;
-    MI_ASSERT(tmax >= 1);
     for (int64_t i3 = 0; i3 < x->ne[3]; ++i3) for (int64_t i2 = 0; i2 < x->ne[2]; ++i2) {
-        const char  * W = (const char *) w->data + (i2/r2)*w->nb[2] + (i3/r3)*w->nb[3];
-        for (int64_t t0 = 0; t0 < Ttot; t0 += tmax) {
-            const int T = (int) ((Ttot - t0) < tmax ? (Ttot - t0) : tmax);
-            const float * X = (const float *)((const char *) x->data + t0*x->nb[1] + i2*x->nb[2] + i3*x->nb[3]);
-            float       * D = (float *)((char *) out->data + t0*out->nb[1] + i2*out->nb[2] + i3*out->nb[3]);
-            const float * R = residual ? (const float *)((const char *) residual->data + t0*residual->nb[1] + i2*residual->nb[2] + i3*residual->nb[3]) : nullptr;
-            const int64_t xs = x->nb[1]/4, ds = out->nb[1]/4, rs = residual ? residual->nb[1]/4 : 0;
-            switch (w->type) {
-                case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
-                case GGML_TYPE_Q5_K: launch_type<GGML_TYPE_Q5_K>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
-                case GGML_TYPE_Q6_K: launch_type<GGML_TYPE_Q6_K>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
-                case GGML_TYPE_Q8_0: launch_type<GGML_TYPE_Q8_0>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
-                case GGML_TYPE_Q4_0: launch_type<GGML_TYPE_Q4_0>(st, T, W, w->nb[1], X, xs, D, ds, R, rs, k, rows); break;
-                default: MI_ABORT("mmvq: unsupported weight type %d", w->type);
-            }
-        }
+        mmvq_launch L{};
+        L.act.X = (const float *)((const char *) x->data + i2*x->nb[2] + i3*x->nb[3]); L.act.xs = x->nb[1]/4;
+        L.k = k; L.n_mat = 1;
+        L.m[0].W = (const char *) w->data + (i2/r2)*w->nb[2] + (i3/r3)*w->nb[3]; L.m[0].row_bytes = w->nb[1]; L.m[0].rows = rows;
+        L.m[0].epi = EPI_F32; L.m[0].out = (char *) out->data + i2*out->nb[2] + i3*out->nb[3]; L.m[0].o_row = 4; L.m[0].o_tok = out->nb[1];
+        if (residual) { L.m[0].res = (const float *)((const char *) residual->data + i2*residual->nb[2] + i3*residual->nb[3]); L.m[0].r_tok = residual->nb[1]/4; }
+        mi_mmvq_run(st, w->type, (int) Ttot, L);
     }
 }

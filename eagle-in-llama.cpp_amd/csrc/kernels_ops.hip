@@ -58,27 +58,41 @@ template <int NW> __device__ __forceinline__ float block_max(float v, float * sh
 // ------------------------------------------------------------------ RMS_NORM (+ fused MUL by a weight row)
 // one 256-thread block per row; y = x * (1/sqrtf(mean + eps)) [ * w ]
 __global__ void __launch_bounds__(256) k_rms_norm(const char * __restrict__ x, char * __restrict__ y, const float * __restrict__ w,
-                                                   int64_t ne00, int64_t ne01, int64_t ne02, int64_t w_ne0,
-                                                   int64_t nb01, int64_t nb02, int64_t nb03, int64_t nb1, int64_t nb2, int64_t nb3, float eps) {
+                                                   int ne00, int ne01, int ne02,
+                                                   int64_t nb01, int64_t nb02, int64_t nb03, int64_t nb1, int64_t nb2, int64_t nb3, float eps, int vec) {
     __shared__ double sh[4];
-    const int64_t row = blockIdx.x;
-    const int64_t i1 = row % ne01, i2 = (row / ne01) % ne02, i3 = row / (ne01 * ne02);
+    const int row = blockIdx.x;
+    const int i1 = row % ne01, i2 = (row / ne01) % ne02, i3 = row / (ne01 * ne02);
     const float * xr = (const float *)(x + i1*nb01 + i2*nb02 + i3*nb03);
     float       * yr = (float *)(y + i1*nb1 + i2*nb2 + i3*nb3);
     double s = 0.0;
-    for (int64_t i = threadIdx.x; i < ne00; i += 256) { const float v = xr[i]; s += (double)(v * v); }
+    if (vec) {
+        for (int i = threadIdx.x*4; i < ne00; i += 1024) { const float4 v = *(const float4 *)(xr + i); s += (double)(v.x*v.x); s += (double)(v.y*v.y); s += (double)(v.z*v.z); s += (double)(v.w*v.w); }
+    } else {
+        for (int i = threadIdx.x; i < ne00; i += 256) { const float v = xr[i]; s += (double)(v * v); }
+    }
     s = block_sum<double, 4>(s, sh);
     const float mean  = (float)(s / (double) ne00);
     const float scale = 1.0f / sqrtf(mean + eps);
-    if (w) { for (int64_t i = threadIdx.x; i < ne00; i += 256) yr[i] = (xr[i] * scale) * w[i % w_ne0]; }
-    else   { for (int64_t i = threadIdx.x; i < ne00; i += 256) yr[i] =  xr[i] * scale; }
+    if (vec) {
+        for (int i = threadIdx.x*4; i < ne00; i += 1024) {
+            float4 v = *(const float4 *)(xr + i);
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            if (w) { const float4 q = *(const float4 *)(w + i); v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
+            *(float4 *)(yr + i) = v;
+        }
+    } else if (w) { for (int i = threadIdx.x; i < ne00; i += 256) yr[i] = (xr[i] * scale) * w[i]; }
+    else          { for (int i = threadIdx.x; i < ne00; i += 256) yr[i] =  xr[i] * scale; }
 }
 void mi_op_rms_norm(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * mul_w, const ggml_tensor * out) {
     const ggml_tensor * s0 = dst->src[0];
     const int64_t rows = s0->ne[1]*s0->ne[2]*s0->ne[3];
     if (rows == 0 || s0->ne[0] == 0) return;
+    MI_ASSERT(!mul_w || mul_w->ne[0] == s0->ne[0]);
+    const bool al = !((uintptr_t) s0->data & 15) && !((uintptr_t) out->data & 15) && !(mul_w && ((uintptr_t) mul_w->data & 15));
+    const int vec = al && s0->ne[0] % 4 == 0 && !(s0->nb[1] & 15) && !(s0->nb[2] & 15) && !(s0->nb[3] & 15) && !(out->nb[1] & 15) && !(out->nb[2] & 15) && !(out->nb[3] & 15);
     k_rms_norm<<<(unsigned) rows, 256, 0, st>>>((const char *) s0->data, (char *) out->data, mul_w ? (const float *) mul_w->data : nullptr,
-        s0->ne[0], s0->ne[1], s0->ne[2], mul_w ? mul_w->ne[0] : 1, s0->nb[1], s0->nb[2], s0->nb[3], out->nb[1], out->nb[2], out->nb[3], mi_op_f32(dst, 0));
+        (int) s0->ne[0], (int) s0->ne[1], (int) s0->ne[2], s0->nb[1], s0->nb[2], s0->nb[3], out->nb[1], out->nb[2], out->nb[3], mi_op_f32(dst, 0), vec);
 }
 
 // ------------------------------------------------------------------ ADD / SUB / MUL / DIV with broadcast of src1
