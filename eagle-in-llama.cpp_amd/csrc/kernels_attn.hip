@@ -95,31 +95,41 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
         for (int i = lane; i < n_kv; i += WAVE) row[i] = rnd16(row[i] * inv);
     }
     __syncthreads();
-    // ---- phase 3: out[d, t] = sum_i V[i, d] * p[t][i]; one wave per output dim, lanes across cells (8 per lane)
-    for (int d = wave; d < D; d += 4) {
-        const char * vr = vb + (int64_t) d * a.v_nb1;
-        float acc[ATT_TT];
+    // ---- phase 3: out[d, t] = sum_i V[i, d] * p[t][i]; a wave takes DU output dims per pass (DU independent 16-byte
+    //      V loads in flight), lanes across cells (8 per lane); blockIdx.z splits the output dims between blocks
+    constexpr int DU = 4;
+    const int dper = D / gridDim.z, dbeg = blockIdx.z * dper;
+    for (int d0 = dbeg + wave*DU; d0 < dbeg + dper; d0 += 4*DU) {
+        float acc[DU][ATT_TT];
 #pragma unroll
-        for (int t = 0; t < ATT_TT; ++t) acc[t] = 0.f;
+        for (int u = 0; u < DU; ++u)
+#pragma unroll
+            for (int t = 0; t < ATT_TT; ++t) acc[u][t] = 0.f;
         for (int i = lane*8; i < n_kv; i += WAVE*8) {
-            float vf[8];
-            const i32x4 vv = *(const i32x4 *)(vr + (int64_t) i * 2);
-            h8_to_f(vv, vf);
+            i32x4 vv[DU];
+#pragma unroll
+            for (int u = 0; u < DU; ++u) vv[u] = *(const i32x4 *)(vb + (int64_t)(d0 + u) * a.v_nb1 + (int64_t) i * 2);
 #pragma unroll
             for (int t = 0; t < ATT_TT; ++t) {
                 if (t >= nt) break;
                 const float4 p0 = *(const float4 *)(sc + t*n_kv + i), p1 = *(const float4 *)(sc + t*n_kv + i + 4);
-                acc[t] += vf[0]*p0.x + vf[1]*p0.y + vf[2]*p0.z + vf[3]*p0.w + vf[4]*p1.x + vf[5]*p1.y + vf[6]*p1.z + vf[7]*p1.w;
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                    float vf[8]; h8_to_f(vv[u], vf);
+                    acc[u][t] += vf[0]*p0.x + vf[1]*p0.y + vf[2]*p0.z + vf[3]*p0.w + vf[4]*p1.x + vf[5]*p1.y + vf[6]*p1.z + vf[7]*p1.w;
+                }
             }
         }
 #pragma unroll
-        for (int t = 0; t < ATT_TT; ++t) {
-            if (t >= nt) break;
-            float v = acc[t];
+        for (int u = 0; u < DU; ++u)
 #pragma unroll
-            for (int o = WAVE/2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-            if (lane == 0) *(float *)((char *) a.out + (int64_t) d*4 + (int64_t) h * a.o_nb1 + (int64_t)(t0 + t) * a.o_nb2) = v;
-        }
+            for (int t = 0; t < ATT_TT; ++t) {
+                if (t >= nt) break;
+                float v = acc[u][t];
+#pragma unroll
+                for (int o = WAVE/2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+                if (lane == 0) *(float *)((char *) a.out + (int64_t)(d0 + u)*4 + (int64_t) h * a.o_nb1 + (int64_t)(t0 + t) * a.o_nb2) = v;
+            }
     }
     (void) shd;
 }
@@ -135,7 +145,9 @@ bool mi_attn_small_supported(const mi_attn_args & a) {
 
 void mi_op_attn_small(hipStream_t st, const mi_attn_args & a) {
     const size_t lds = (size_t) a.n_kv * ATT_TT * 4;
-    const dim3 grid(a.H, (a.T + ATT_TT - 1) / ATT_TT);
+    const int tiles = (a.T + ATT_TT - 1) / ATT_TT;
+    const int dsplit = (a.H * tiles >= 256) ? 1 : ((a.H * tiles >= 128) ? 2 : 4);     // more blocks when heads x tiles under-fill the chip
+    const dim3 grid(a.H, tiles, dsplit);
     static std::once_flag once;
     std::call_once(once, [] {
         HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 152*1024));

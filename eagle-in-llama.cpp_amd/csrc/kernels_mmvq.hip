@@ -480,13 +480,13 @@ static void launch_one(hipStream_t st, const mmvq_launch & L) {
     int total = 0;
     if (DUAL) total = (L.m[0].rows + MMVQ_R - 1) / MMVQ_R;
     else for (int i = 0; i < L.n_mat; ++i) total += (L.m[i].rows + MMVQ_R - 1) / MMVQ_R;
-    int max_blocks_cu = (int) ((160*1024) / (lds + 512));
-    if (max_blocks_cu < 1) max_blocks_cu = 1;
-    const int cap_waves = 32 / NW;
-    if (max_blocks_cu > cap_waves) max_blocks_cu = cap_waves;
-    if (max_blocks_cu > 4) max_blocks_cu = 4;
+    // Few, fat, persistent blocks: every block pays the activation prologue once, so the grid is sized to the
+    // chip (two 512-thread blocks per CU when LDS allows), not to the row count; waves stride over row groups.
+    int blocks_cu = (int) ((160*1024) / (lds + 512));
+    if (blocks_cu > 2) blocks_cu = 2;
+    if (blocks_cu < 1) blocks_cu = 1;
     int grid = (total + NW - 1) / NW;
-    const int cap = 256 * max_blocks_cu;
+    const int cap = 256 * blocks_cu;
     if (grid > cap) grid = cap;
     if (grid < 1) return;
     auto fn = k_mmvq<TYPE, T, NW, DUAL>;
@@ -494,9 +494,8 @@ static void launch_one(hipStream_t st, const mmvq_launch & L) {
     fn<<<grid, NW*WAVE, lds, st>>>(L);
 }
 template <int TYPE, int T> static void launch_T(hipStream_t st, const mmvq_launch & L) {
-    const size_t lds = act_lds_bytes(wt<TYPE>::K, T, L.k);
-    if (L.swiglu) { if (lds > 36*1024) launch_one<TYPE, T, 8, true >(st, L); else launch_one<TYPE, T, 4, true >(st, L); }
-    else          { if (lds > 36*1024) launch_one<TYPE, T, 8, false>(st, L); else launch_one<TYPE, T, 4, false>(st, L); }
+    if (L.swiglu) launch_one<TYPE, T, 8, true >(st, L);
+    else          launch_one<TYPE, T, 8, false>(st, L);
 }
 template <int TYPE> static void launch_type(hipStream_t st, int T, const mmvq_launch & L) {
     switch (T) {
