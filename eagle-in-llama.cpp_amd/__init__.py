@@ -331,11 +331,11 @@ class Model:
         _model_sigs().eh_model_kv_seq_rm(self.h, seq, p0, p1)
 
     def timers(self, reset=False):
-        t = (C.c_double * 5)()
+        t = (C.c_double * 8)()
         _model_sigs().eh_model_timers(self.h, t)
         if reset:
             _model_sigs().eh_model_timers_reset(self.h)
-        return dict(build_us=t[0], upload_us=t[1], compute_us=t[2], download_us=t[3], n_decode=int(t[4]))
+        return dict(build_us=t[0], upload_us=t[1], compute_us=t[2], download_us=t[3], n_decode=int(t[4]), issue_us=t[5], wait_us=t[6])
 
 
 def spec_generate(target, draft, prompt, n_predict, n_draft=5, p_min=0.0):

@@ -142,8 +142,8 @@ EH_API void eh_model_kv_clear(void * m) { ((Model *) m)->kv.clear(); }
 EH_API void eh_model_kv_seq_rm(void * m, int seq, int p0, int p1) { ((Model *) m)->kv.seq_rm(seq, p0, p1); }
 EH_API void eh_model_kv_seq_cp(void * m, int a, int b, int p0, int p1) { ((Model *) m)->kv.seq_cp(a, b, p0, p1); }
 EH_API void eh_model_kv_seq_keep(void * m, int seq) { ((Model *) m)->kv.seq_keep(seq); }
-EH_API void eh_model_timers(void * mp, double * t) { Model * m = (Model *) mp; t[0] = m->t_build_us; t[1] = m->t_upload_us; t[2] = m->t_compute_us; t[3] = m->t_download_us; t[4] = (double) m->n_decode; }
-EH_API void eh_model_timers_reset(void * mp) { Model * m = (Model *) mp; m->t_build_us = m->t_upload_us = m->t_compute_us = m->t_download_us = 0; m->n_decode = 0; }
+EH_API void eh_model_timers(void * mp, double * t) { Model * m = (Model *) mp; t[0] = m->t_build_us; t[1] = m->t_upload_us; t[2] = m->t_compute_us; t[3] = m->t_download_us; t[4] = (double) m->n_decode; t[5] = m->gctx->t_issue_us; t[6] = m->gctx->t_wait_us; }
+EH_API void eh_model_timers_reset(void * mp) { Model * m = (Model *) mp; m->t_build_us = m->t_upload_us = m->t_compute_us = m->t_download_us = 0; m->n_decode = 0; m->gctx->t_issue_us = m->gctx->t_wait_us = 0; }
 
 // Speculative generation.  stats: ST_* doubles.  Returns tokens generated, < 0 on error.
 EH_API int eh_spec_run(void * tgt, void * dft, const int32_t * prompt, int n_prompt, int n_predict, int n_draft, float p_min,

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 
 namespace mh {
 
@@ -226,6 +227,15 @@ enum ggml_status Ctx::compute_async() {
     graph.nodes = node_array.data(); graph.order = GGML_CGRAPH_EVAL_ORDER_LEFT_TO_RIGHT;
     return be->be->iface.graph_compute(be->be, &graph);
 }
-enum ggml_status Ctx::compute() { enum ggml_status s = compute_async(); be->synchronize(); return s; }
+enum ggml_status Ctx::compute() {
+    const auto t0 = std::chrono::steady_clock::now();
+    enum ggml_status s = compute_async();
+    const auto t1 = std::chrono::steady_clock::now();
+    be->synchronize();
+    const auto t2 = std::chrono::steady_clock::now();
+    t_issue_us += std::chrono::duration<double, std::micro>(t1 - t0).count();
+    t_wait_us  += std::chrono::duration<double, std::micro>(t2 - t1).count();
+    return s;
+}
 
 } // namespace mh

@@ -91,6 +91,7 @@ struct Ctx {
     void get(const ggml_tensor * t, void * data, size_t offset, size_t size);
     enum ggml_status compute();                  // graph_compute over `nodes` + synchronize
     enum ggml_status compute_async();
+    double t_issue_us = 0, t_wait_us = 0;        // host time inside graph_compute vs waiting for the device
 
   private:
     ggml_tensor * op_result(int op, int type, const int64_t * ne, ggml_tensor * a, ggml_tensor * b = nullptr, ggml_tensor * c = nullptr);

@@ -14,7 +14,7 @@ for rep in range(2):
     tgt.timers(reset=True)
     plain, ps = ea.plain_generate(tgt, prompt, 128)
     tm = tgt.timers()
-    print("plain: %.1f tok/s  prompt %.1f ms; per-decode: build %.1f us upload %.1f compute %.1f download %.1f nodes %d" % (ps["n_predict"]/ps["t_decode_us"]*1e6, ps["t_prompt_us"]/1e3, tm["build_us"]/tm["n_decode"], tm["upload_us"]/tm["n_decode"], tm["compute_us"]/tm["n_decode"], tm["download_us"]/tm["n_decode"], tgt.n_nodes), flush=True)
+    print("plain: %.1f tok/s  prompt %.1f ms; per-decode: build %.1f us upload %.1f compute %.1f download %.1f nodes %d issue %.1f wait %.1f" % (ps["n_predict"]/ps["t_decode_us"]*1e6, ps["t_prompt_us"]/1e3, tm["build_us"]/tm["n_decode"], tm["upload_us"]/tm["n_decode"], tm["compute_us"]/tm["n_decode"], tm["download_us"]/tm["n_decode"], tgt.n_nodes, tm["issue_us"]/tm["n_decode"], tm["wait_us"]/tm["n_decode"]), flush=True)
 for nd in (3,5,7):
     tgt.timers(reset=True); dft.timers(reset=True)
     spec, ss = ea.spec_generate(tgt, dft, prompt, 128, n_draft=nd)

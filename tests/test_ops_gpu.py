@@ -190,8 +190,17 @@ def test_attention_subgraph_tree_mask(ea, gpu):
     res = g.cont(g.permute(g.mul_mat(tv, sm), 0, 2, 1, 3))
     g.alloc(); g.set(tq, q); g.set(tk, kc); g.set(tv, vc); g.set(tm, mask); g.compute()
     got = g.get(res).reshape(T, H, d)
-    assert rel(got, z["at_y"]) < 1e-3
-    assert rel(g.get(sm).reshape(H, T, n_kv), z["sm_y"] if False else orc.soft_max(g.get(kqt).reshape(H, T, n_kv), mask, float(z["at_scale"]))) < 2e-6
-    # masked cells get exactly zero probability
+    assert rel(got, z["at_y"]) < 1e-3            # the fused single-kernel path (intermediates are never materialised)
+    assert rel(got, orc.attention(q, kc, vc, mask, float(z["at_scale"]), Hkv)) < 1e-3
+    # same graph with the intermediates flagged as graph outputs: runs node by node, so they can be inspected
+    g = ea.Graph(gpu)
+    tq = g.tensor(ea.F32, d, H, T); tk = g.tensor(ea.F16, d, n_kv, Hkv); tv = g.tensor(ea.F16, n_kv, d, Hkv); tm = g.tensor(ea.F32, n_kv, 64)
+    kqt = g.mul_mat(tk, g.permute(tq, 0, 2, 1, 3))
+    sm = g.soft_max(kqt, tm, float(z["at_scale"]))
+    res = g.cont(g.permute(g.mul_mat(tv, sm), 0, 2, 1, 3))
+    ea.host().eh_tensor_set_flags(kqt, 2); ea.host().eh_tensor_set_flags(sm, 2)
+    g.alloc(); g.set(tq, q); g.set(tk, kc); g.set(tv, vc); g.set(tm, mask); g.compute()
+    assert rel(g.get(res).reshape(T, H, d), z["at_y"]) < 1e-3
     p = g.get(sm).reshape(H, T, n_kv)
-    assert np.all(p[:, np.isinf(mask[:T])] == 0)
+    assert rel(p, orc.soft_max(g.get(kqt).reshape(H, T, n_kv), mask, float(z["at_scale"]))) < 2e-6
+    assert np.all(p[:, np.isinf(mask[:T])] == 0)   # masked cells get exactly zero probability
