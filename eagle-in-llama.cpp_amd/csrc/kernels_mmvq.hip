@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include <mutex>
 #include <unordered_set>
+#include <vector>
 
 #define WAVE 64
 typedef int   i32x4 __attribute__((ext_vector_type(4)));
@@ -471,6 +472,37 @@ static void ensure_lds_attr(const void * fn, size_t bytes) {
     HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
     g_attr_done.insert(fn);
 }
+// ---- optional HIP-event profile of every mat-vec launch (bench.py roofline; off by default, zero cost when off)
+struct prof_rec { hipEvent_t a, b; double bytes; };
+static bool g_prof_on = false;
+static std::vector<prof_rec> g_prof;
+static std::mutex g_prof_mu;
+extern "C" __attribute__((visibility("default"))) void ggml_backend_mi355x_profile_begin(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto & r : g_prof) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
+    g_prof.clear(); g_prof_on = true;
+}
+// out[0] = total kernel milliseconds, out[1] = total algorithmic bytes; returns the number of launches
+extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_profile_end(double * out) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    double ms = 0, bytes = 0;
+    for (auto & r : g_prof) { float t = 0; if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; bytes += r.bytes; } (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
+    const int n = (int) g_prof.size();
+    g_prof.clear();
+    if (out) { out[0] = ms; out[1] = bytes; }
+    return n;
+}
+// algorithmic bytes of one launch: weights once + fp32 activations once + outputs once
+static double launch_bytes(const mmvq_launch & L, int T, bool dual) {
+    double b = (double) T * L.k * 4;
+    const int nm = dual ? 2 : L.n_mat;
+    for (int i = 0; i < nm; ++i) b += (double) L.m[i].rows * L.m[i].row_bytes;
+    if (dual) b += (double) L.m[0].rows * T * 4;
+    else for (int i = 0; i < nm; ++i) b += (double) L.m[i].rows * T * ((L.m[i].epi == EPI_F16 || L.m[i].epi == EPI_ROPE_F16) ? 2 : 4);
+    return b;
+}
+
 static inline size_t lds_total(bool ktype, int T, int k, int NW) { return act_lds_bytes(ktype, T, k) + 8 + (size_t) NW*8 + (size_t) T*4 + 16; }
 
 template <int TYPE, int T, int NW, bool DUAL>
@@ -491,6 +523,14 @@ static void launch_one(hipStream_t st, const mmvq_launch & L) {
     if (grid < 1) return;
     auto fn = k_mmvq<TYPE, T, NW, DUAL>;
     ensure_lds_attr((const void *) fn, lds);
+    if (g_prof_on) {
+        prof_rec r; HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b)); r.bytes = launch_bytes(L, T, DUAL);
+        HIP_CHECK(hipEventRecord(r.a, st));
+        fn<<<grid, NW*WAVE, lds, st>>>(L);
+        HIP_CHECK(hipEventRecord(r.b, st));
+        std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(r);
+        return;
+    }
     fn<<<grid, NW*WAVE, lds, st>>>(L);
 }
 template <int TYPE, int T> static void launch_T(hipStream_t st, const mmvq_launch & L) {

@@ -47,6 +47,12 @@ GGML_MI355X_API int                ggml_backend_mi355x_device_count(void);
  * (R/ggml/include/ggml-backend.h:188); tensor_split has one entry per device, NULL => even split */
 GGML_MI355X_API ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device, const float * tensor_split);
 
+/* measurement hook (not part of the reference's interface): HIP-event timing of every quantised mat-vec launch
+ * between begin/end, on the stream the kernels are launched on.  out[0] = kernel milliseconds, out[1] = algorithmic
+ * bytes (weights + fp32 activations + outputs); returns the number of launches.  Used by bench.py. */
+GGML_MI355X_API void ggml_backend_mi355x_profile_begin(void);
+GGML_MI355X_API int  ggml_backend_mi355x_profile_end(double * out);
+
 #ifdef __cplusplus
 }
 #endif
