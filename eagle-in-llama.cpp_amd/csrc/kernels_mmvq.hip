@@ -36,50 +36,66 @@ __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdg
 __device__ __forceinline__ int dot16(i32x4 a, i32x4 b) {
     int s = dot4(a.x, b.x, 0); s = dot4(a.y, b.y, s); s = dot4(a.z, b.z, s); return dot4(a.w, b.w, s);
 }
-__device__ __forceinline__ float wave_sum_f(float v) {
+// ---- wave64 reductions on the DPP path (no LDS traffic, unlike ds_bpermute-based __shfl):
+// quad_perm xor1 / xor2, row_half_mirror, row_mirror fold a 16-lane row; the four row sums are combined through readlane.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
+template <int CTRL> __device__ __forceinline__ int   dpp_i(int v)   { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+#define DPP_XOR1 0xB1      /* quad_perm [1,0,3,2] */
+#define DPP_XOR2 0x4E      /* quad_perm [2,3,0,1] */
+#define DPP_HMIR 0x141     /* row_half_mirror: lane i <-> 7-i  (acts as xor 4 once quads are uniform) */
+#define DPP_MIR  0x140     /* row_mirror:      lane i <-> 15-i (acts as xor 8 once half rows are uniform) */
+__device__ __forceinline__ float row_sum_f(float v) { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HMIR>(v); v += dpp_f<DPP_MIR>(v); return v; }
+__device__ __forceinline__ float wave_sum_f(float v) {        // result in every lane
+    v = row_sum_f(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+__device__ __forceinline__ float row_max_f(float v) { v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_HMIR>(v)); v = fmaxf(v, dpp_f<DPP_MIR>(v)); return v; }
+__device__ __forceinline__ float wave_max_f(float v) {
+    v = row_max_f(v);
+    return fmaxf(fmaxf(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), fmaxf(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = min(v, dpp_i<DPP_XOR1>(v)); v = min(v, dpp_i<DPP_XOR2>(v)); v = min(v, dpp_i<DPP_HMIR>(v)); v = min(v, dpp_i<DPP_MIR>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    int2 p = *(int2 *) &v;
+#define DSTEP(C) { int2 q; q.x = dpp_i<C>(p.x); q.y = dpp_i<C>(p.y); v += *(double *) &q; p = *(int2 *) &v; }
+    DSTEP(DPP_XOR1) DSTEP(DPP_XOR2) DSTEP(DPP_HMIR) DSTEP(DPP_MIR)
+#undef DSTEP
+    double r = 0.0;
 #pragma unroll
-    for (int o = WAVE/2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    for (int l = 0; l < 64; l += 16) { int2 q; q.x = __builtin_amdgcn_readlane(p.x, l); q.y = __builtin_amdgcn_readlane(p.y, l); r += *(double *) &q; }
+    return r;
 }
 
-template <int TYPE> struct wt;
-template <> struct wt<GGML_TYPE_Q4_K> { static constexpr int BS = 144, QK = 256, STEP = 2048; static constexpr bool K = true;  };
-template <> struct wt<GGML_TYPE_Q5_K> { static constexpr int BS = 176, QK = 256, STEP = 2048; static constexpr bool K = true;  };
-template <> struct wt<GGML_TYPE_Q6_K> { static constexpr int BS = 210, QK = 256, STEP = 2048; static constexpr bool K = true;  };
-template <> struct wt<GGML_TYPE_Q8_0> { static constexpr int BS = 34,  QK = 32,  STEP = 1024; static constexpr bool K = false; };
-template <> struct wt<GGML_TYPE_Q4_0> { static constexpr int BS = 18,  QK = 32,  STEP = 2048; static constexpr bool K = false; };
-
 // LDS image of the quantised activations
-struct act_lds {
-    const int8_t * q;   // [T][k]
-    const float  * d;   // [T][k/256] (K types) or [T][k/32] (Q8_0 semantics, value already rounded through fp16)
-    const short  * bs;  // [T][k/16]  (K types only)
-    int k;
-};
 static inline size_t act_lds_bytes(bool ktype, int T, int k) {
     return ktype ? (size_t) T*k + (size_t) T*(k/256)*4 + (size_t) T*(k/16)*2 : (size_t) T*k + (size_t) T*(k/32)*4;
 }
 
 // ---------------------------------------------------------------- prologue: (rms_norm * w) -> quantise X[T][k] into LDS
-// Activation source of a launch.  With `norm` the block first recomputes RMS_NORM (+ MUL by the norm weight) of
-// every token row itself -- sum of squares in double exactly like ggml_compute_forward_rms_norm_f32 -- so the
-// normalised fp32 tensor never goes to HBM and the separate norm launch disappears.
-template <int T, int NW> __device__ __forceinline__ void row_scales(const act_src & a, int k, float * sc /*LDS [T]*/, double * red /*LDS [NW]*/) {
+// Activation source of a launch (struct act_src, kernels.h).  With `norm` the block first recomputes RMS_NORM
+// (+ MUL by the norm weight) of every token row itself -- sum of squares in double exactly like
+// ggml_compute_forward_rms_norm_f32 -- so the normalised fp32 tensor never goes to HBM and the separate norm launch
+// disappears.
+template <int T, int NW> __device__ __forceinline__ void row_scales(const act_src & a, int k, float * sc /*LDS [T]*/, double * red /*LDS [NW][T]*/) {
     const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    double s[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        double s = 0.0;
-        for (int i = threadIdx.x*4; i < k; i += NW*WAVE*4) {
+    for (int t = 0; t < T; ++t) s[t] = 0.0;
+    for (int i = threadIdx.x*4; i < k; i += NW*WAVE*4) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
             const float4 v = *(const float4 *)(a.X + t*a.xs + i);
-            s += (double)(v.x*v.x); s += (double)(v.y*v.y); s += (double)(v.z*v.z); s += (double)(v.w*v.w);
+            s[t] += (double)(v.x*v.x); s[t] += (double)(v.y*v.y); s[t] += (double)(v.z*v.z); s[t] += (double)(v.w*v.w);
         }
-#pragma unroll
-        for (int o = WAVE/2; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
-        if (lane == 0) red[wave] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) { double tot = 0.0; for (int w = 0; w < NW; ++w) tot += red[w]; const float mean = (float)(tot / (double) k); sc[t] = 1.0f / sqrtf(mean + a.eps); }
-        __syncthreads();
     }
+#pragma unroll
+    for (int t = 0; t < T; ++t) { const double r = wave_sum_d(s[t]); if (lane == 0) red[wave*T + t] = r; }
+    __syncthreads();
+    if (threadIdx.x < T) { double tot = 0.0; for (int w = 0; w < NW; ++w) tot += red[w*T + threadIdx.x]; const float mean = (float)(tot / (double) k); sc[threadIdx.x] = 1.0f / sqrtf(mean + a.eps); }
+    __syncthreads();
 }
 __device__ __forceinline__ float4 fetch4(const act_src & a, const float * sc, int t, int e) {
     float4 v = *(const float4 *)(a.X + t*a.xs + e);
@@ -110,14 +126,10 @@ template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const 
             float amax = 0.0f; int first = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float ax = fabsf(xv[j]); if (ax > amax) { amax = ax; first = j; } }
-            float wmax = amax;
-#pragma unroll
-            for (int o = WAVE/2; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, WAVE));
-            int key = (amax == wmax) ? (lane*4 + first) : (1 << 20);      // lowest index holding the maximum
-#pragma unroll
-            for (int o = WAVE/2; o > 0; o >>= 1) key = min(key, __shfl_xor(key, o, WAVE));
+            const float wmax = wave_max_f(amax);
+            const int key = wave_min_i((amax == wmax) ? (lane*4 + first) : (1 << 20));     // lowest index holding the maximum
             const float cand = (first == 0) ? xv[0] : (first == 1) ? xv[1] : (first == 2) ? xv[2] : xv[3];
-            const float mx = __shfl(cand, (key >> 2) & 63, WAVE);
+            const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand), (key >> 2) & 63));
             int packed = 0; int s = 0; float dd = 0.0f;
             if (wmax != 0.0f) {
                 const float iscale = -127.f / mx;
@@ -125,9 +137,9 @@ template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const 
                 for (int j = 0; j < 4; ++j) { int qi = __float2int_rn(iscale * xv[j]); qi = min(127, qi); s += qi; packed |= (qi & 0xff) << (8*j); }
                 dd = 1.0f / iscale;
             }
-            *(int *)(q + (size_t) t*k + sb*256 + lane*4) = packed;
-            s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE);
-            if ((lane & 3) == 0) bs[(size_t) t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
+            *(int *)(q + t*k + sb*256 + lane*4) = packed;
+            s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s);
+            if ((lane & 3) == 0) bs[t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
             if (lane == 0) d[t*nsb + sb] = dd;
         }
     }
@@ -136,7 +148,7 @@ template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const 
 __device__ __forceinline__ void q80_unit(const float4 v, int8_t * qdst, float * ddst, int lane, bool write) {
     const float xv[4] = { v.x, v.y, v.z, v.w };
     float amax = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 2, WAVE)); amax = fmaxf(amax, __shfl_xor(amax, 4, WAVE));
+    amax = fmaxf(amax, dpp_f<DPP_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_XOR2>(amax)); amax = fmaxf(amax, dpp_f<DPP_HMIR>(amax));   // 8 lanes = one block of 32
     const float dd = amax / 127.f;
     const float id = dd ? 1.0f/dd : 0.0f;
     int packed = 0;
@@ -160,170 +172,140 @@ template <int T, int NW> __device__ __forceinline__ void quant_q80_to_lds(const 
             const int u = u0 + p*NW;
             if (u >= nu) break;
             const int t = u / nch, ch = u - t*nch, e = ch*256 + lane*4;
-            q80_unit(vv[p], q + (size_t) t*k + e, d + t*nb + e/32, lane, e < k);
+            q80_unit(vv[p], q + t*k + e, d + t*nb + e/32, lane, e < k);
         }
     }
 }
 
 // ---------------------------------------------------------------- per-type weight fragments
-// A "unit" is what one lane loads per k-step: a 16-byte slice of quants plus the scales it needs.
+// A fragment is what one lane owns of one weight row for one k-step: a 16-byte slice of quants plus the scales that
+// go with it.  load() issues the global loads (nothing else), decode() unpacks nibbles and scales ONCE, mac() is the
+// per-token work: integer dot products against the int8 activations the caller read from LDS (shared by all the
+// fragments of the step), two int->float conversions and two FMAs.  Lanes past the end of a ragged last k-step keep
+// d = 0 and a clamped (valid) address instead of branching.
+struct act_regs { i32x4 lo, hi; int b0, b1; float dy; };
+
 template <int TYPE> struct wfrag;
 
 // Q4_K: lane (sb, c): c in 0..7 -> quant bytes [16c,16c+16): group g=c/2 (sub-blocks 2g | 2g+1 in low | high nibbles), half h=c%2
 template <> struct wfrag<GGML_TYPE_Q4_K> {
-    i32x4 hdr, qs; bool on;
-    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
-        const int sb = step*8 + (lane >> 3), c = lane & 7;
-        on = sb < k/256;
-        if (on) { const char * b = row + (size_t) sb*144; hdr = ld16(b); qs = ld16(b + 16 + 16*c); }
-        else    { hdr = (i32x4)(0); qs = (i32x4)(0); }
+    i32x4 hdr, qs; int sc0, sc1, m0, m1; float dw, mw;
+    static __device__ __forceinline__ int nunits(int k) { return k / 256; }                      // units of a row: super-blocks
+    static __device__ __forceinline__ bool valid(int unit, int lane, int k) { return unit < k / 256; }
+    static __device__ __forceinline__ void act_off(int lane, int & sub, int & alo, int & ahi, int & blo, int & bhi) {
+        const int c = lane & 7, g = c >> 1, h = c & 1; sub = lane >> 3; alo = 64*g + 16*h; ahi = alo + 32; blo = 4*g + h; bhi = blo + 2;
     }
-    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
-        if (!on) return;
-        const int sb = step*8 + (lane >> 3), c = lane & 7, g = c >> 1, h = c & 1;
-        const float dw = h2f((uint16_t)(hdr.x & 0xffff)), mw = h2f((uint16_t)((uint32_t) hdr.x >> 16));
-        // 6-bit scale/min unpack (get_scale_min_k4, R/ggml/src/ggml-quants.c:631-638) for j = 2g, 2g+1
-        const uint32_t s0 = hdr.y, s1 = hdr.z, s2 = hdr.w;             // scales[0..3], [4..7], [8..11]
-        auto sbyte = [&](int i) -> uint32_t { const uint32_t w = i < 4 ? s0 : (i < 8 ? s1 : s2); return (w >> (8*(i & 3))) & 0xff; };
-        int sc[2], mn[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int j = 2*g + e;
-            if (j < 4) { sc[e] = sbyte(j) & 63; mn[e] = sbyte(j + 4) & 63; }
-            else       { sc[e] = (sbyte(j + 4) & 0xF) | ((sbyte(j - 4) >> 6) << 4); mn[e] = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
-        }
-        const i32x4 lo = qs & 0x0F0F0F0F, hi = (qs >> 4) & 0x0F0F0F0F;
-        const int eo = sb*256 + 64*g + 16*h;                            // element offset of the low-nibble group
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int8_t * aq = a.q + (size_t) t*a.k + eo;
-            const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 32);
-            const short * bsp = a.bs + (size_t) t*(a.k/16) + sb*16 + 4*g + h;
-            const float dy = a.d[t*(a.k/256) + sb];
-            const int si = sc[0]*dot16(lo, alo) + sc[1]*dot16(hi, ahi);
-            const int mi = mn[0]*(int) bsp[0] + mn[1]*(int) bsp[2];
-            acc[t] += (dw*dy)*(float) si - (mw*dy)*(float) mi;
-        }
+    __device__ __forceinline__ void load(const char * row, int unit, int lane, int) { const char * b = row + unit*144; hdr = ld16(b); qs = ld16(b + 16 + 16*(lane & 7)); }
+    __device__ __forceinline__ void decode(int lane, bool valid) {
+        const int g = (lane & 7) >> 1;
+        const uint32_t u0 = hdr.y, u1 = hdr.z, u2 = hdr.w;                                           // scales[0..3], [4..7], [8..11]
+        // get_scale_min_k4 (R/ggml/src/ggml-quants.c:631-638) for all eight sub-blocks at once, as the CPU's utmp/kmask trick does
+        const uint32_t s_lo = u0 & 0x3f3f3f3fu, s_hi = (u2 & 0x0f0f0f0fu) | ((u0 >> 2) & 0x30303030u);
+        const uint32_t m_lo = u1 & 0x3f3f3f3fu, m_hi = ((u2 >> 4) & 0x0f0f0f0fu) | ((u1 >> 2) & 0x30303030u);
+        const uint32_t sp = ((g < 2 ? s_lo : s_hi) >> (16*(g & 1))) & 0xffffu, mp = ((g < 2 ? m_lo : m_hi) >> (16*(g & 1))) & 0xffffu;
+        sc0 = sp & 0xff; sc1 = sp >> 8; m0 = mp & 0xff; m1 = mp >> 8;
+        dw = valid ? h2f((uint16_t)(hdr.x & 0xffff)) : 0.f; mw = valid ? h2f((uint16_t)((uint32_t) hdr.x >> 16)) : 0.f;
+        const i32x4 q = qs; qs = q & 0x0F0F0F0F; hdr = (q >> 4) & 0x0F0F0F0F;                         // qs = low nibbles, hdr = high nibbles from here on
+    }
+    __device__ __forceinline__ float mac(const act_regs & a) const {
+        const int si = sc0*dot16(qs, a.lo) + sc1*dot16(hdr, a.hi);
+        const int mi = m0*a.b0 + m1*a.b1;
+        return (dw*a.dy)*(float) si - (mw*a.dy)*(float) mi;
     }
 };
-
 // Q5_K: as Q4_K plus one high bit per element from qh[32]
 template <> struct wfrag<GGML_TYPE_Q5_K> {
-    i32x4 hdr, qh, qs; bool on;
-    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
-        const int sb = step*8 + (lane >> 3), c = lane & 7;
-        on = sb < k/256;
-        if (on) { const char * b = row + (size_t) sb*176; hdr = ld16(b); qh = ld16(b + 16 + 16*(c & 1)); qs = ld16(b + 48 + 16*c); }
-        else    { hdr = (i32x4)(0); qh = (i32x4)(0); qs = (i32x4)(0); }
+    i32x4 hdr, qh, qs; int sc0, sc1, m0, m1; float dw, mw;
+    static __device__ __forceinline__ int nunits(int k) { return k / 256; }
+    static __device__ __forceinline__ bool valid(int unit, int lane, int k) { return unit < k / 256; }
+    static __device__ __forceinline__ void act_off(int lane, int & sub, int & alo, int & ahi, int & blo, int & bhi) {
+        const int c = lane & 7, g = c >> 1, h = c & 1; sub = lane >> 3; alo = 64*g + 16*h; ahi = alo + 32; blo = 4*g + h; bhi = blo + 2;
     }
-    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
-        if (!on) return;
-        const int sb = step*8 + (lane >> 3), c = lane & 7, g = c >> 1, h = c & 1;
-        const float dw = h2f((uint16_t)(hdr.x & 0xffff)), mw = h2f((uint16_t)((uint32_t) hdr.x >> 16));
-        const uint32_t s0 = hdr.y, s1 = hdr.z, s2 = hdr.w;
-        auto sbyte = [&](int i) -> uint32_t { const uint32_t w = i < 4 ? s0 : (i < 8 ? s1 : s2); return (w >> (8*(i & 3))) & 0xff; };
-        int sc[2], mn[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int j = 2*g + e;
-            if (j < 4) { sc[e] = sbyte(j) & 63; mn[e] = sbyte(j + 4) & 63; }
-            else       { sc[e] = (sbyte(j + 4) & 0xF) | ((sbyte(j - 4) >> 6) << 4); mn[e] = (sbyte(j + 4) >> 4) | ((sbyte(j) >> 6) << 4); }
-        }
-        const i32x4 lo = (qs & 0x0F0F0F0F)        | (((qh >> (2*g))     & 0x01010101) << 4);
-        const i32x4 hi = ((qs >> 4) & 0x0F0F0F0F) | (((qh >> (2*g + 1)) & 0x01010101) << 4);
-        const int eo = sb*256 + 64*g + 16*h;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int8_t * aq = a.q + (size_t) t*a.k + eo;
-            const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 32);
-            const short * bsp = a.bs + (size_t) t*(a.k/16) + sb*16 + 4*g + h;
-            const float dy = a.d[t*(a.k/256) + sb];
-            const int si = sc[0]*dot16(lo, alo) + sc[1]*dot16(hi, ahi);
-            const int mi = mn[0]*(int) bsp[0] + mn[1]*(int) bsp[2];
-            acc[t] += (dw*dy)*(float) si - (mw*dy)*(float) mi;
-        }
+    __device__ __forceinline__ void load(const char * row, int unit, int lane, int) { const char * b = row + unit*176; const int c = lane & 7; hdr = ld16(b); qh = ld16(b + 16 + 16*(c & 1)); qs = ld16(b + 48 + 16*c); }
+    __device__ __forceinline__ void decode(int lane, bool valid) {
+        const int g = (lane & 7) >> 1;
+        const uint32_t u0 = hdr.y, u1 = hdr.z, u2 = hdr.w;
+        const uint32_t s_lo = u0 & 0x3f3f3f3fu, s_hi = (u2 & 0x0f0f0f0fu) | ((u0 >> 2) & 0x30303030u);
+        const uint32_t m_lo = u1 & 0x3f3f3f3fu, m_hi = ((u2 >> 4) & 0x0f0f0f0fu) | ((u1 >> 2) & 0x30303030u);
+        const uint32_t sp = ((g < 2 ? s_lo : s_hi) >> (16*(g & 1))) & 0xffffu, mp = ((g < 2 ? m_lo : m_hi) >> (16*(g & 1))) & 0xffffu;
+        sc0 = sp & 0xff; sc1 = sp >> 8; m0 = mp & 0xff; m1 = mp >> 8;
+        dw = valid ? h2f((uint16_t)(hdr.x & 0xffff)) : 0.f; mw = valid ? h2f((uint16_t)((uint32_t) hdr.x >> 16)) : 0.f;
+        const i32x4 q = qs, hb = qh;
+        qs  = (q & 0x0F0F0F0F)        | (((hb >> (2*g))     & 0x01010101) << 4);
+        hdr = ((q >> 4) & 0x0F0F0F0F) | (((hb >> (2*g + 1)) & 0x01010101) << 4);
+    }
+    __device__ __forceinline__ float mac(const act_regs & a) const {
+        const int si = sc0*dot16(qs, a.lo) + sc1*dot16(hdr, a.hi);
+        const int mi = m0*a.b0 + m1*a.b1;
+        return (dw*a.dy)*(float) si - (mw*a.dy)*(float) mi;
     }
 };
-
 // Q6_K: lane (sb, c): half n=c/4, cc=c%4: ql bytes [64n+16cc, +16): low nibbles -> elements 128n+16cc.., high -> +64;
-// the two high bits come from qh[32n + 16(cc%2) ..] at bit offsets 2(cc/2) and 2(cc/2)+4; value - 32.
+// the two high bits come from qh[32n + 16(cc%2) ..] at bit offsets 2(cc/2) and 2(cc/2)+4; value - 32 (folded in through bsums).
 template <> struct wfrag<GGML_TYPE_Q6_K> {
-    i32x4 ql, qh; int sc_lo, sc_hi; float dw; bool on;
-    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
-        const int sb = step*8 + (lane >> 3), c = lane & 7, n = c >> 2, cc = c & 3;
-        on = sb < k/256;
-        if (on) {
-            const char * b = row + (size_t) sb*210;
-            ql = ld16(b + 64*n + 16*cc); qh = ld16(b + 128 + 32*n + 16*(cc & 1));
-            const int8_t * s = (const int8_t *)(b + 192 + 8*n + cc);
-            sc_lo = s[0]; sc_hi = s[4];
-            uint16_t dh; __builtin_memcpy(&dh, b + 208, 2); dw = h2f(dh);
-        } else { ql = (i32x4)(0); qh = (i32x4)(0); sc_lo = sc_hi = 0; dw = 0.f; }
+    i32x4 ql, qh; int sc0, sc1; float dw;
+    static __device__ __forceinline__ int nunits(int k) { return k / 256; }
+    static __device__ __forceinline__ bool valid(int unit, int lane, int k) { return unit < k / 256; }
+    static __device__ __forceinline__ void act_off(int lane, int & sub, int & alo, int & ahi, int & blo, int & bhi) {
+        const int c = lane & 7, n = c >> 2, cc = c & 3; sub = lane >> 3; alo = 128*n + 16*cc; ahi = alo + 64; blo = 8*n + cc; bhi = blo + 4;
     }
-    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
-        if (!on) return;
-        const int sb = step*8 + (lane >> 3), c = lane & 7, n = c >> 2, cc = c & 3;
-        const int sh = 2*(cc >> 1);
-        const i32x4 lo = (ql & 0x0F0F0F0F)        | (((qh >> sh)       & 0x03030303) << 4);
-        const i32x4 hi = ((ql >> 4) & 0x0F0F0F0F) | (((qh >> (sh + 4)) & 0x03030303) << 4);
-        const int eo = sb*256 + 128*n + 16*cc;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int8_t * aq = a.q + (size_t) t*a.k + eo;
-            const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 64);
-            const short * bsp = a.bs + (size_t) t*(a.k/16) + sb*16 + 8*n + cc;
-            const float dy = a.d[t*(a.k/256) + sb];
-            const int si = sc_lo*(dot16(lo, alo) - 32*(int) bsp[0]) + sc_hi*(dot16(hi, ahi) - 32*(int) bsp[4]);
-            acc[t] += (dw*dy)*(float) si;
-        }
+    __device__ __forceinline__ void load(const char * row, int unit, int lane, int) {
+        const char * b = row + unit*210; const int c = lane & 7, n = c >> 2, cc = c & 3;
+        ql = ld16(b + 64*n + 16*cc); qh = ld16(b + 128 + 32*n + 16*(cc & 1));
+        const int8_t * s = (const int8_t *)(b + 192 + 8*n + cc);
+        sc0 = s[0]; sc1 = s[4];
+        uint16_t dh; __builtin_memcpy(&dh, b + 208, 2); dw = h2f(dh);
+    }
+    __device__ __forceinline__ void decode(int lane, bool valid) {
+        const int sh = 2*((lane & 3) >> 1);
+        const i32x4 l = ql, hb = qh;
+        ql = (l & 0x0F0F0F0F)        | (((hb >> sh)       & 0x03030303) << 4);
+        qh = ((l >> 4) & 0x0F0F0F0F) | (((hb >> (sh + 4)) & 0x03030303) << 4);
+        if (!valid) dw = 0.f;
+    }
+    __device__ __forceinline__ float mac(const act_regs & a) const {
+        const int si = sc0*(dot16(ql, a.lo) - 32*a.b0) + sc1*(dot16(qh, a.hi) - 32*a.b1);
+        return (dw*a.dy)*(float) si;
     }
 };
-
-// Q8_0: two lanes per 32-element block (16 int8 each); the block's int32 sum is completed across the pair
-// before the single fp32 multiply, as in ggml_vec_dot_q8_0_q8_0.
+// Q8_0: two lanes per 32-element block (16 int8 each); the block's int32 sum is completed across the lane pair
+// before the single fp32 multiply, as in ggml_vec_dot_q8_0_q8_0; only the even lane accumulates.
 template <> struct wfrag<GGML_TYPE_Q8_0> {
-    i32x4 qs; float dw; bool on;
-    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
-        const int blk = step*32 + (lane >> 1), h = lane & 1;
-        on = blk < k/32;
-        if (on) { const char * b = row + (size_t) blk*34; uint16_t dh; __builtin_memcpy(&dh, b, 2); dw = h2f(dh); qs = ld16(b + 2 + 16*h); }
-        else    { qs = (i32x4)(0); dw = 0.f; }
+    i32x4 qs; float dw;
+    static __device__ __forceinline__ int nunits(int k) { return (k/32 + 3) / 4; }                 // unit = 4 blocks: 8 lanes
+    static __device__ __forceinline__ bool valid(int unit, int lane, int k) { return unit*4 + ((lane & 7) >> 1) < k/32; }
+    static __device__ __forceinline__ void act_off(int lane, int & sub, int & alo, int & ahi, int & blo, int & bhi) {
+        const int c = lane & 7; sub = lane >> 3; alo = 32*(c >> 1) + 16*(c & 1); ahi = alo; blo = c >> 1; bhi = 0;
     }
-    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
-        const int blk = step*32 + (lane >> 1), h = lane & 1;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            int s = 0; float dy = 0.f;
-            if (on) { s = dot16(qs, *(const i32x4 *)(a.q + (size_t) t*a.k + blk*32 + 16*h)); dy = a.d[t*(a.k/32) + blk]; }
-            s += __shfl_xor(s, 1, WAVE);
-            if (h == 0) acc[t] += (float) s * (dw*dy);
-        }
+    __device__ __forceinline__ void load(const char * row, int unit, int lane, int k) {
+        const int c = lane & 7; const char * b = row + min(unit*4 + (c >> 1), k/32 - 1)*34; uint16_t dh; __builtin_memcpy(&dh, b, 2); dw = h2f(dh); qs = ld16(b + 2 + 16*(c & 1));
+    }
+    __device__ __forceinline__ void decode(int lane, bool valid) { if (!valid || (lane & 1)) dw = 0.f; }
+    __device__ __forceinline__ float mac(const act_regs & a) const {
+        int s = dot16(qs, a.lo);
+        s += dpp_i<DPP_XOR1>(s);
+        return (float) s * (dw*a.dy);
     }
 };
-
 // Q4_0: one lane per block: low nibbles -> elements 0..15, high -> 16..31, value - 8.
 template <> struct wfrag<GGML_TYPE_Q4_0> {
-    i32x4 qs; float dw; bool on;
-    __device__ __forceinline__ void load(const char * row, int step, int lane, int k) {
-        const int blk = step*64 + lane;
-        on = blk < k/32;
-        if (on) { const char * b = row + (size_t) blk*18; uint16_t dh; __builtin_memcpy(&dh, b, 2); dw = h2f(dh); qs = ld16(b + 2); }
-        else    { qs = (i32x4)(0); dw = 0.f; }
+    i32x4 qs, hi; float dw;
+    static __device__ __forceinline__ int nunits(int k) { return (k/32 + 7) / 8; }                 // unit = 8 blocks: 8 lanes
+    static __device__ __forceinline__ bool valid(int unit, int lane, int k) { return unit*8 + (lane & 7) < k/32; }
+    static __device__ __forceinline__ void act_off(int lane, int & sub, int & alo, int & ahi, int & blo, int & bhi) {
+        const int c = lane & 7; sub = lane >> 3; alo = 32*c; ahi = alo + 16; blo = c; bhi = 0;
     }
-    template <int T> __device__ __forceinline__ void dot(const act_lds & a, int step, int lane, float * acc) const {
-        if (!on) return;
-        const int blk = step*64 + lane;
-        const i32x4 lo = qs & 0x0F0F0F0F, hi = (qs >> 4) & 0x0F0F0F0F;
+    __device__ __forceinline__ void load(const char * row, int unit, int lane, int k) {
+        const char * b = row + min(unit*8 + (lane & 7), k/32 - 1)*18; uint16_t dh; __builtin_memcpy(&dh, b, 2); dw = h2f(dh); qs = ld16(b + 2);
+    }
+    __device__ __forceinline__ void decode(int lane, bool valid) { const i32x4 q = qs; qs = q & 0x0F0F0F0F; hi = (q >> 4) & 0x0F0F0F0F; if (!valid) dw = 0.f; }
+    __device__ __forceinline__ float mac(const act_regs & a) const {
         const i32x4 ones = (i32x4)(0x01010101);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int8_t * aq = a.q + (size_t) t*a.k + blk*32;
-            const i32x4 alo = *(const i32x4 *) aq, ahi = *(const i32x4 *)(aq + 16);
-            const int s = dot16(lo, alo) + dot16(hi, ahi) - 8*(dot16(ones, alo) + dot16(ones, ahi));
-            acc[t] += ((float) s * dw) * a.d[t*(a.k/32) + blk];      // (sumi*dx)*dy, ggml-cpu-quants.c:2606
-        }
+        const int s = dot16(qs, a.lo) + dot16(hi, a.hi) - 8*(dot16(ones, a.lo) + dot16(ones, a.hi));
+        return ((float) s * dw) * a.dy;                                                              // (sumi*dx)*dy, ggml-cpu-quants.c:2606
     }
 };
+template <int TYPE> struct act_kind { static constexpr bool K = (TYPE == GGML_TYPE_Q4_K || TYPE == GGML_TYPE_Q5_K || TYPE == GGML_TYPE_Q6_K); };
 
 // ---------------------------------------------------------------- the kernel
 // One launch = up to three weight matrices of ONE quant type sharing the same activations (wq|wk|wv, or gate|up),
@@ -333,132 +315,160 @@ template <> struct wfrag<GGML_TYPE_Q4_0> {
 //   EPI_ROPE_F16  RoPE, then f16 store straight into the K cache view          (Kcur -> cpy -> k_cache_view)
 //   EPI_F16       f16 store with row/token strides: the transposed V cache     (Vcur -> transpose -> cpy)
 // DUAL: matrices 0/1 are ffn_gate/ffn_up, a wave computes the same rows of both and writes silu(g)*u (SwiGLU).
-constexpr int MMVQ_R = 2;   // weight rows per wave per pass (RoPE pairs live in one wave)
-
-template <int TYPE, int T, bool DUAL> struct acc_t { float g[MMVQ_R][T]; float u[DUAL ? MMVQ_R : 1][DUAL ? T : 1]; };
+//
+// Geometry: a wave-step covers 8 units of a row (8 lanes x 16 B each, contiguous in HBM); a wave owns MMVQ_R rows at
+// a time and walks their k-steps one by one; the loads of step s+1 are in flight while step s is computed
+// (two fragment sets), and the very first loads are issued before the activation prologue.
+// weight rows per wave per pass: 2 (RoPE pairs live in one wave); 1 in DUAL mode, where a wave already carries two matrices
+template <bool DUAL> struct rows_per_wave { static constexpr int R = DUAL ? 1 : 2; };
 
 template <int TYPE, int T, int NW, bool DUAL>
 __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using WT = wt<TYPE>;
+    constexpr bool KQ = act_kind<TYPE>::K;
+    constexpr int MMVQ_R = rows_per_wave<DUAL>::R;
+    constexpr int NF = MMVQ_R * (DUAL ? 2 : 1);                 // fragments per k-step
     const int k = L.k;
     int8_t * lq = (int8_t *) smem;
-    float  * ld = (float *)(smem + (size_t) T*k);
-    short  * lb = (short *)((char *) ld + (size_t) T*(WT::K ? k/256 : k/32)*4);
-    char   * tail = (char *) lb + (WT::K ? (size_t) T*(k/16)*2 : 0);
+    float  * ld = (float *)(smem + T*k);
+    short  * lb = (short *)((char *) ld + T*(KQ ? k/256 : k/32)*4);
+    char   * tail = (char *) lb + (KQ ? T*(k/16)*2 : 0);
     tail = (char *)(((uintptr_t) tail + 7) & ~(uintptr_t) 7);
     double * red = (double *) tail;
-    float  * sc  = (float *)(tail + NW*8);
+    float  * sc  = (float *)(tail + NW*T*8);
 
     const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
-    const int nsteps = (k + WT::STEP - 1) / WT::STEP;
+    const int nunits = wfrag<TYPE>::nunits(k);
+    const int nsteps = (nunits + 7) / 8;
+    int sub, alo, ahi, blo, bhi;
+    wfrag<TYPE>::act_off(lane, sub, alo, ahi, blo, bhi);
     // group -> (matrix, first row)
     const int c0 = (L.m[0].rows + MMVQ_R - 1) / MMVQ_R;
     const int c1 = (!DUAL && L.n_mat > 1) ? (L.m[1].rows + MMVQ_R - 1) / MMVQ_R : 0;
     const int c2 = (!DUAL && L.n_mat > 2) ? (L.m[2].rows + MMVQ_R - 1) / MMVQ_R : 0;
     const int total = c0 + c1 + c2;
-    auto locate = [&](int g, int & mi, int & row0) { if (g < c0) { mi = 0; row0 = g*MMVQ_R; } else if (g < c0 + c1) { mi = 1; row0 = (g - c0)*MMVQ_R; } else { mi = 2; row0 = (g - c0 - c1)*MMVQ_R; } };
+    const int gstride = gridDim.x*NW;
 
-    // issue the first weight loads BEFORE the activation prologue: their HBM latency hides behind it
-    wfrag<TYPE> f[2][MMVQ_R], fu[DUAL ? 2 : 1][DUAL ? MMVQ_R : 1];
-    int g = blockIdx.x*NW + wave;
-    if (g < total) {
-        int mi, row0; locate(g, mi, row0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int r = 0; r < MMVQ_R; ++r) {
-                f[u][r].load(L.m[mi].W + (size_t) min(row0 + r, L.m[mi].rows - 1) * L.m[mi].row_bytes, u, lane, (u < nsteps) ? k : 0);
-                if (DUAL) fu[u][r].load(L.m[1].W + (size_t) min(row0 + r, L.m[1].rows - 1) * L.m[1].row_bytes, u, lane, (u < nsteps) ? k : 0);
-            }
-    }
-    if (L.act.norm) row_scales<T, NW>(L.act, k, sc, red);
-    if (WT::K) quant_q8K_to_lds<T, NW>(L.act, sc, k, lq, ld, lb);
-    else       quant_q80_to_lds<T, NW>(L.act, sc, k, lq, ld);
-    __syncthreads();
-    act_lds a; a.q = lq; a.d = ld; a.bs = lb; a.k = k;
-
-    bool first = true;
-    for (; g < total; g += gridDim.x*NW, first = false) {
-        int mi, row0; locate(g, mi, row0);
-        const mmvq_mat & M = L.m[mi];
-        float acc[MMVQ_R][T], accu[DUAL ? MMVQ_R : 1][DUAL ? T : 1];
-#pragma unroll
-        for (int r = 0; r < MMVQ_R; ++r)
-#pragma unroll
-            for (int t = 0; t < T; ++t) { acc[r][t] = 0.f; if (DUAL) accu[r][t] = 0.f; }
-        const char * rp[MMVQ_R], * rpu[MMVQ_R];
+    const char * rp[NF];
+    auto set_rows = [&](int g, int & mi, int & row0) {
+        if (g < c0) { mi = 0; row0 = g*MMVQ_R; } else if (g < c0 + c1) { mi = 1; row0 = (g - c0)*MMVQ_R; } else { mi = 2; row0 = (g - c0 - c1)*MMVQ_R; }
 #pragma unroll
         for (int r = 0; r < MMVQ_R; ++r) {
-            rp[r] = M.W + (size_t) min(row0 + r, M.rows - 1) * M.row_bytes;
-            rpu[r] = DUAL ? L.m[1].W + (size_t) min(row0 + r, L.m[1].rows - 1) * L.m[1].row_bytes : nullptr;
+            rp[r] = L.m[mi].W + (size_t) min(row0 + r, L.m[mi].rows - 1) * L.m[mi].row_bytes;
+            if (DUAL) rp[(DUAL ? MMVQ_R : 0) + r] = L.m[1].W + (size_t) min(row0 + r, L.m[1].rows - 1) * L.m[1].row_bytes;
         }
+    };
+    auto load_step = [&](wfrag<TYPE> * f, int s) {
+        const int unit = min(s*8 + sub, nunits - 1);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) f[i].load(rp[i], unit, lane, k);
+    };
+
+    wfrag<TYPE> fa[NF], fb[NF];
+    int g = blockIdx.x*NW + wave, mi = 0, row0 = 0;
+    if (g < total) { set_rows(g, mi, row0); load_step(fa, 0); }          // in flight across the prologue
+    if (L.act.norm) row_scales<T, NW>(L.act, k, sc, red);
+    if (KQ) quant_q8K_to_lds<T, NW>(L.act, sc, k, lq, ld, lb);
+    else    quant_q80_to_lds<T, NW>(L.act, sc, k, lq, ld);
+    __syncthreads();
+
+    while (g < total) {
+        const mmvq_mat & M = L.m[mi];
+        float acc[NF][T];
+#pragma unroll
+        for (int i = 0; i < NF; ++i)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[i][t] = 0.f;
+        const int gn = g + gstride;
         for (int s = 0; s < nsteps; s += 2) {
-            if (!(first && s == 0)) {
+            // ---- even step: fa holds step s; prefetch step s+1 (or the next group's step 0) into fb
+            const bool more1 = s + 1 < nsteps;
+            if (more1) load_step(fb, s + 1);
+            {
+                const int unit = s*8 + sub; const bool valid = wfrag<TYPE>::valid(unit, lane, k); const int uc = min(unit, nunits - 1);
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int i = 0; i < NF; ++i) fa[i].decode(lane, valid);
 #pragma unroll
-                    for (int r = 0; r < MMVQ_R; ++r) {
-                        f[u][r].load(rp[r], s + u, lane, (s + u < nsteps) ? k : 0);
-                        if (DUAL) fu[u][r].load(rpu[r], s + u, lane, (s + u < nsteps) ? k : 0);
-                    }
-            }
+                for (int t = 0; t < T; ++t) {
+                    act_regs a;
+                    const int8_t * aq = lq + t*k + uc*(KQ ? 256 : (TYPE == GGML_TYPE_Q8_0 ? 128 : 256));
+                    a.lo = *(const i32x4 *)(aq + alo); a.hi = *(const i32x4 *)(aq + ahi);
+                    if (KQ) { const short * bp = lb + t*(k/16) + uc*16; a.b0 = bp[blo]; a.b1 = bp[bhi]; a.dy = ld[t*(k/256) + uc]; }
+                    else    { a.b0 = a.b1 = 0; a.dy = ld[t*(k/32) + uc*(TYPE == GGML_TYPE_Q8_0 ? 4 : 8) + blo]; }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < MMVQ_R; ++r) {
-                    f[u][r].template dot<T>(a, s + u, lane, acc[r]);
-                    if (DUAL) fu[u][r].template dot<T>(a, s + u, lane, accu[r]);
+                    for (int i = 0; i < NF; ++i) acc[i][t] += fa[i].mac(a);
                 }
+            }
+            if (!more1) break;
+            // ---- odd step: fb holds step s+1; prefetch step s+2 into fa
+            if (s + 2 < nsteps) load_step(fa, s + 2);
+            {
+                const int unit = (s + 1)*8 + sub; const bool valid = wfrag<TYPE>::valid(unit, lane, k); const int uc = min(unit, nunits - 1);
+#pragma unroll
+                for (int i = 0; i < NF; ++i) fb[i].decode(lane, valid);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    act_regs a;
+                    const int8_t * aq = lq + t*k + uc*(KQ ? 256 : (TYPE == GGML_TYPE_Q8_0 ? 128 : 256));
+                    a.lo = *(const i32x4 *)(aq + alo); a.hi = *(const i32x4 *)(aq + ahi);
+                    if (KQ) { const short * bp = lb + t*(k/16) + uc*16; a.b0 = bp[blo]; a.b1 = bp[bhi]; a.dy = ld[t*(k/256) + uc]; }
+                    else    { a.b0 = a.b1 = 0; a.dy = ld[t*(k/32) + uc*(TYPE == GGML_TYPE_Q8_0 ? 4 : 8) + blo]; }
+#pragma unroll
+                    for (int i = 0; i < NF; ++i) acc[i][t] += fb[i].mac(a);
+                }
+            }
         }
+        // ---- next group's first loads go out before this group's reduction/epilogue
+        const int cur_row0 = row0;
+        int nmi = mi, nrow0 = row0;
+        if (gn < total) { set_rows(gn, nmi, nrow0); load_step(fa, 0); }
         // ---- reduce: every lane ends up with every sum
 #pragma unroll
-        for (int r = 0; r < MMVQ_R; ++r)
+        for (int i = 0; i < NF; ++i)
 #pragma unroll
-            for (int t = 0; t < T; ++t) { acc[r][t] = wave_sum_f(acc[r][t]); if (DUAL) accu[r][t] = wave_sum_f(accu[r][t]); }
+            for (int t = 0; t < T; ++t) acc[i][t] = wave_sum_f(acc[i][t]);
         // ---- epilogue: lane t finishes token t
-        const bool ok1 = row0 + 1 < M.rows;
+        const bool ok1 = cur_row0 + 1 < M.rows;
         if (DUAL) {
-            float * out = (float *) L.m[0].out;
 #pragma unroll
             for (int t = 0; t < T; ++t) if (lane == t) {
-                const float g0 = acc[0][t], g1 = acc[1][t];
-                *(float *)((char *) out + (size_t) row0*L.m[0].o_row + (size_t) t*L.m[0].o_tok) = (g0 / (1.0f + expf(-g0))) * accu[0][t];
-                if (ok1) *(float *)((char *) out + (size_t)(row0 + 1)*L.m[0].o_row + (size_t) t*L.m[0].o_tok) = (g1 / (1.0f + expf(-g1))) * accu[1][t];
+                const float g0 = acc[0][t];
+                *(float *)(L.m[0].out + (size_t) cur_row0*L.m[0].o_row + (size_t) t*L.m[0].o_tok) = (g0 / (1.0f + expf(-g0))) * acc[NF - 1][t];
             }
         } else if (M.epi == EPI_F32) {
 #pragma unroll
             for (int t = 0; t < T; ++t) if (lane == t) {
-                float v0 = acc[0][t], v1 = acc[1][t];
-                if (M.res) { v0 += M.res[(size_t) t*M.r_tok + row0]; if (ok1) v1 += M.res[(size_t) t*M.r_tok + row0 + 1]; }
-                *(float *)(M.out + (size_t) row0*M.o_row + (size_t) t*M.o_tok) = v0;
-                if (ok1) *(float *)(M.out + (size_t)(row0 + 1)*M.o_row + (size_t) t*M.o_tok) = v1;
+                float v0 = acc[0][t], v1 = acc[NF > 1 ? 1 : 0][t];
+                if (M.res) { v0 += M.res[(size_t) t*M.r_tok + cur_row0]; if (ok1) v1 += M.res[(size_t) t*M.r_tok + cur_row0 + 1]; }
+                *(float *)(M.out + (size_t) cur_row0*M.o_row + (size_t) t*M.o_tok) = v0;
+                if (ok1) *(float *)(M.out + (size_t)(cur_row0 + 1)*M.o_row + (size_t) t*M.o_tok) = v1;
             }
         } else if (M.epi == EPI_F16) {
 #pragma unroll
             for (int t = 0; t < T; ++t) if (lane == t) {
-                *(__half *)(M.out + (size_t) row0*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(acc[0][t]);
-                if (ok1) *(__half *)(M.out + (size_t)(row0 + 1)*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(acc[1][t]);
+                *(__half *)(M.out + (size_t) cur_row0*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(acc[0][t]);
+                if (ok1) *(__half *)(M.out + (size_t)(cur_row0 + 1)*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(acc[NF > 1 ? 1 : 0][t]);
             }
         } else {   // RoPE on the pair (row0, row0+1): theta by the reference's float recurrence (ggml_rope_cache_init)
-            const int ip = (row0 % L.rope.head_dim) >> 1;
+            const int ip = (cur_row0 % L.rope.head_dim) >> 1;
 #pragma unroll
             for (int t = 0; t < T; ++t) if (lane == t) {
                 float theta = (float) L.rope.pos[t];
                 for (int j = 0; j < ip; ++j) theta *= L.rope.theta_scale;
                 const float th = L.rope.freq_scale * theta;
                 const float c = cosf(th) * L.rope.attn_factor, sn = sinf(th) * L.rope.attn_factor;
-                const float x0 = acc[0][t], x1 = acc[1][t];
+                const float x0 = acc[0][t], x1 = acc[NF > 1 ? 1 : 0][t];
                 const float y0 = x0*c - x1*sn, y1 = x0*sn + x1*c;
                 if (M.epi == EPI_ROPE_F32) {
-                    *(float *)(M.out + (size_t) row0*M.o_row + (size_t) t*M.o_tok) = y0;
-                    *(float *)(M.out + (size_t)(row0 + 1)*M.o_row + (size_t) t*M.o_tok) = y1;
+                    *(float *)(M.out + (size_t) cur_row0*M.o_row + (size_t) t*M.o_tok) = y0;
+                    *(float *)(M.out + (size_t)(cur_row0 + 1)*M.o_row + (size_t) t*M.o_tok) = y1;
                 } else {
-                    *(__half *)(M.out + (size_t) row0*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(y0);
-                    *(__half *)(M.out + (size_t)(row0 + 1)*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(y1);
+                    *(__half *)(M.out + (size_t) cur_row0*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(y0);
+                    *(__half *)(M.out + (size_t)(cur_row0 + 1)*M.o_row + (size_t) t*M.o_tok) = __float2half_rn(y1);
                 }
             }
         }
+        g = gn; mi = nmi; row0 = nrow0;
     }
 }
 
@@ -503,12 +513,13 @@ static double launch_bytes(const mmvq_launch & L, int T, bool dual) {
     return b;
 }
 
-static inline size_t lds_total(bool ktype, int T, int k, int NW) { return act_lds_bytes(ktype, T, k) + 8 + (size_t) NW*8 + (size_t) T*4 + 16; }
+static inline size_t lds_total(bool ktype, int T, int k, int NW) { return act_lds_bytes(ktype, T, k) + 8 + (size_t) NW*T*8 + (size_t) T*4 + 16; }
 
 template <int TYPE, int T, int NW, bool DUAL>
 static void launch_one(hipStream_t st, const mmvq_launch & L) {
-    const size_t lds = lds_total(wt<TYPE>::K, T, L.k, NW);
+    const size_t lds = lds_total(act_kind<TYPE>::K, T, L.k, NW);
     MI_ASSERT(lds <= 160*1024);
+    constexpr int MMVQ_R = rows_per_wave<DUAL>::R;
     int total = 0;
     if (DUAL) total = (L.m[0].rows + MMVQ_R - 1) / MMVQ_R;
     else for (int i = 0; i < L.n_mat; ++i) total += (L.m[i].rows + MMVQ_R - 1) / MMVQ_R;
