@@ -44,15 +44,16 @@ template <int CTRL> __device__ __forceinline__ int   dpp_i(int v)   { return __b
 #define DPP_XOR2 0x4E      /* quad_perm [2,3,0,1] */
 #define DPP_HMIR 0x141     /* row_half_mirror: lane i <-> 7-i  (acts as xor 4 once quads are uniform) */
 #define DPP_MIR  0x140     /* row_mirror:      lane i <-> 15-i (acts as xor 8 once half rows are uniform) */
+__device__ __forceinline__ float rdl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }   // readlane is an int builtin: bit-cast, never convert
 __device__ __forceinline__ float row_sum_f(float v) { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HMIR>(v); v += dpp_f<DPP_MIR>(v); return v; }
 __device__ __forceinline__ float wave_sum_f(float v) {        // result in every lane
     v = row_sum_f(v);
-    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+    return (rdl_f(v, 0) + rdl_f(v, 16)) + (rdl_f(v, 32) + rdl_f(v, 48));
 }
 __device__ __forceinline__ float row_max_f(float v) { v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_HMIR>(v)); v = fmaxf(v, dpp_f<DPP_MIR>(v)); return v; }
 __device__ __forceinline__ float wave_max_f(float v) {
     v = row_max_f(v);
-    return fmaxf(fmaxf(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), fmaxf(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    return fmaxf(fmaxf(rdl_f(v, 0), rdl_f(v, 16)), fmaxf(rdl_f(v, 32), rdl_f(v, 48)));
 }
 __device__ __forceinline__ int wave_min_i(int v) {
     v = min(v, dpp_i<DPP_XOR1>(v)); v = min(v, dpp_i<DPP_XOR2>(v)); v = min(v, dpp_i<DPP_HMIR>(v)); v = min(v, dpp_i<DPP_MIR>(v));
