@@ -10,6 +10,7 @@
 //   dlopen protocol R/ggml/src/ggml-backend-impl.h:215-247 and R/ggml/src/ggml-backend-reg.cpp:229-247
 #include "mi355x_common.h"
 #include "ggml_mi355x.h"
+#include "kernels.h"
 #include <mutex>
 #include <vector>
 #include <string>
@@ -148,6 +149,7 @@ static void be_free(ggml_backend_t b) {
     set_device(c->device);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->scratch) HIP_CHECK(hipFree(c->scratch));
+    if (c->act_cache) { if (c->act_cache->pool) HIP_CHECK(hipFree(c->act_cache->pool)); delete c->act_cache; }
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c; delete b;
 }
@@ -223,6 +225,9 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t d, const char *) {
     c->device = dc->device;
     HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     snprintf(c->name, sizeof(c->name), "%s", dc->name);
+    c->act_cache = new mi_act_cache;
+    c->act_cache->slot_bytes = 512*1024;                                   // T = 8, k = 28672 (70B ffn_down) needs 262 KB
+    HIP_CHECK(hipMalloc((void **) &c->act_cache->pool, c->act_cache->slot_bytes * MI_ACT_SLOTS));
     ggml_backend * b = new ggml_backend;
     b->guid = &g_guid; b->iface = g_be_iface; b->device = d; b->context = c;
     return b;

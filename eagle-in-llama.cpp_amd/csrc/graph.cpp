@@ -267,7 +267,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
             if      (nx->src[0] == t && is_f32(nx->src[1]) && mi_same_shape(nx->src[1], t) && nx->src[1]->nb[0] == 4) res = nx->src[1];
             else if (nx->src[1] == t && is_f32(nx->src[0]) && mi_same_shape(nx->src[0], t) && nx->src[0]->nb[0] == 4) res = nx->src[0];
         }
-        if (res) { mi_op_mul_mat_q(st, t, res, nx); c.done[i + 1] = 1; } else mi_op_mul_mat_q(st, t, nullptr, t);
+        if (res) { mi_op_mul_mat_q(st, t, res, nx, ctx->act_cache); c.done[i + 1] = 1; } else mi_op_mul_mat_q(st, t, nullptr, t, ctx->act_cache);
         return true;
     }
     const int k = (int) w0->ne[0], T = (int) x->ne[1];
@@ -301,7 +301,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
                     member g0 = mem[0], g1 = mem[q]; g0.epi = EPI_F32; g0.out = mul; g0.res = nullptr; g1.epi = EPI_F32; g1.out = mul; g1.res = nullptr;
                     fill_mat(L.m[0], g0); fill_mat(L.m[1], g1);
                     L.m[0].o_row = 4; L.m[0].o_tok = mul->nb[1];
-                    mi_mmvq_run(st, w0->type, T, L);
+                    mi_mmvq_run(st, w0->type, T, L, ctx->act_cache, ap.rms ? (const void *) ap.rms : (const void *) x);
                     c.done[i] = c.done[c.idx(silu)] = c.done[mem[q].node] = c.done[c.idx(mul)] = 1;
                     return true;
                 }
@@ -340,7 +340,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
         L.rope.theta_scale = powf(mi_op_f32(rope0, 5), -2.0f / mi_op_i32(rope0, 1));
         L.rope.freq_scale = mi_op_f32(rope0, 6); L.rope.attn_factor = mi_op_f32(rope0, 8);
     }
-    mi_mmvq_run(st, w0->type, T, L);
+    mi_mmvq_run(st, w0->type, T, L, ctx->act_cache, ap.rms ? (const void *) ap.rms : (const void *) x);
     for (int q = 0; q < keep; ++q) { c.done[sel[q].node] = 1; for (int s : sel[q].swallowed) c.done[s] = 1; }
     return true;
 }
@@ -388,6 +388,7 @@ static bool run_attention(mi_backend_ctx * ctx, gctx & c, int i) {
 enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
     gctx c(g);
     const int n = c.n;
+    ctx->act_cache->epoch++;
     hipStream_t st = ctx->stream;
     static const bool no_fuse = getenv("GGML_MI355X_NO_FUSION") != nullptr;
     const bool fuse = !no_fuse;
@@ -414,7 +415,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
             } break;
             case GGML_OP_MUL_MAT: {
                 if (mi_mul_mat_q_supported_type(t->src[0]->type)) {
-                    if (!run_mmvq_group(ctx, c, i, fuse)) mi_op_mul_mat_q(st, t, nullptr, t);
+                    if (!run_mmvq_group(ctx, c, i, fuse)) mi_op_mul_mat_q(st, t, nullptr, t, ctx->act_cache);
                 } else {
                     if (fuse && run_attention(ctx, c, i)) break;
                     mi_op_mul_mat_f(st, t);

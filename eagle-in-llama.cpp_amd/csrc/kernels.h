@@ -21,6 +21,7 @@ void mi_op_silu_mul (hipStream_t st, const ggml_tensor * gate, const ggml_tensor
 enum { EPI_F32 = 0, EPI_ROPE_F32 = 1, EPI_ROPE_F16 = 2, EPI_F16 = 3 };
 struct act_src {                        // activations of a mat-vec launch (see kernels_mmvq.hip)
     const float * X; int64_t xs; const float * norm_w; int norm; float eps;
+    const char * pre;                  // non-NULL: activations already quantised by mi_quant_act (image in HBM scratch)
 };
 struct mmvq_mat {
     const char * W; int64_t row_bytes; int rows; int epi;
@@ -29,10 +30,17 @@ struct mmvq_mat {
 };
 struct mmvq_rope { const int32_t * pos; int head_dim; float theta_scale, freq_scale, attn_factor; };
 struct mmvq_launch { act_src act; int k; int n_mat; int swiglu; mmvq_mat m[3]; mmvq_rope rope; };
+#define MI_ACT_SLOTS 8
+struct mi_act_cache {                  // quantised-activation images in HBM scratch (see mi_mmvq_run)
+    char * pool = nullptr; size_t slot_bytes = 0; int next = 0; uint64_t epoch = 0;
+    struct entry { const void * key; uint64_t epoch; int t0, T, kq, k; } e[MI_ACT_SLOTS] = {};
+};
 int  mi_mmvq_max_tokens(int type, int k);
-void mi_mmvq_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L);
+size_t mi_act_image_bytes(int type, int T, int k);
+void mi_quant_act(hipStream_t st, int type, int T, const act_src & a, int k, char * out);
+void mi_mmvq_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L, mi_act_cache * cache, const void * key);
 // quantised weight x f32 activations; residual (nullable) is added in the epilogue (fused ADD)
-void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out);
+void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out, mi_act_cache * cache);
 // f16 / f32 / bf16 src0 x f32 src1 (attention K.q, V.p and unquantised weights)
 void mi_op_mul_mat_f(hipStream_t st, const ggml_tensor * dst);
 bool mi_mul_mat_q_supported_type(int type);

@@ -54,23 +54,25 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
             for (int j = 0; j < 8; ++j) qr[t][j] = 0.f;
         }
     }
-    for (int i0 = wave*CPW; i0 < n_kv; i0 += 4*CPW) {
-        const int i = i0 + sub;
-        float kf[8];
-        if (i < n_kv) { const i32x4 kv = *(const i32x4 *)(kb + (int64_t) i * a.k_nb1 + dc*16); h8_to_f(kv, kf); }
-        else {
+    constexpr int KU = 4;                                             // K rows in flight per lane
+    for (int i0 = wave*CPW; i0 < n_kv; i0 += 4*CPW*KU) {
+        i32x4 kv[KU];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kf[j] = 0.f;
-        }
+        for (int u = 0; u < KU; ++u) { const int i = i0 + u*4*CPW + sub; kv[u] = (i < n_kv) ? *(const i32x4 *)(kb + (int64_t) i * a.k_nb1 + dc*16) : (i32x4)(0); }
 #pragma unroll
-        for (int t = 0; t < ATT_TT; ++t) {
-            if (t >= nt) break;
-            float s = 0.f;
+        for (int u = 0; u < KU; ++u) {
+            const int i = i0 + u*4*CPW + sub;
+            float kf[8]; h8_to_f(kv[u], kf);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += kf[j] * qr[t][j];
+            for (int t = 0; t < ATT_TT; ++t) {
+                if (t >= nt) break;
+                float s = 0.f;
 #pragma unroll
-            for (int o = LPC/2; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
-            if (dc == 0 && i < n_kv) sc[t*n_kv + i] = s;
+                for (int j = 0; j < 8; ++j) s += kf[j] * qr[t][j];
+#pragma unroll
+                for (int o = LPC/2; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
+                if (dc == 0 && i < n_kv) sc[t*n_kv + i] = s;
+            }
         }
     }
     __syncthreads();

@@ -71,6 +71,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // LDS image of the quantised activations
+__host__ __device__ static inline size_t act_img_bytes(bool ktype, int T, int k) {
+    return ktype ? (size_t) T*k + (size_t) T*(k/256)*4 + (size_t) T*(k/16)*2 : (size_t) T*k + (size_t) T*(k/32)*4;
+}
 static inline size_t act_lds_bytes(bool ktype, int T, int k) {
     return ktype ? (size_t) T*k + (size_t) T*(k/256)*4 + (size_t) T*(k/16)*2 : (size_t) T*k + (size_t) T*(k/32)*4;
 }
@@ -110,17 +113,17 @@ __device__ __forceinline__ float4 fetch4(const act_src & a, const float * sc, in
 // Q8_K rule: the scale comes from the FIRST element of largest magnitude, iscale = -127/max,
 // q = min(127, rne(iscale*x)), d = 1/iscale, bsums over groups of 16.  One wave = one 256-element super-block;
 // loads for PB super-blocks are issued before the first reduction so their latencies overlap.
-template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, short * bs) {
-    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, short * bs, int ubeg, int ustr) {
+    const int lane = threadIdx.x % WAVE;
     const int nsb = k / 256, nu = T*nsb;
     constexpr int PB = 4;
-    for (int u0 = wave; u0 < nu; u0 += NW*PB) {
+    for (int u0 = ubeg; u0 < nu; u0 += ustr*PB) {
         float4 vv[PB];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) { const int u = u0 + p*NW; if (u < nu) { const int t = u / nsb, sb = u - t*nsb; vv[p] = fetch4(a, sc, t, sb*256 + lane*4); } }
+        for (int p = 0; p < PB; ++p) { const int u = u0 + p*ustr; if (u < nu) { const int t = u / nsb, sb = u - t*nsb; vv[p] = fetch4(a, sc, t, sb*256 + lane*4); } }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int u = u0 + p*NW;
+            const int u = u0 + p*ustr;
             if (u >= nu) break;
             const int t = u / nsb, sb = u - t*nsb;
             const float xv[4] = { vv[p].x, vv[p].y, vv[p].z, vv[p].w };
@@ -157,20 +160,20 @@ __device__ __forceinline__ void q80_unit(const float4 v, int8_t * qdst, float * 
     for (int j = 0; j < 4; ++j) { const int qi = (int) roundf(xv[j]*id); packed |= (qi & 0xff) << (8*j); }
     if (write) { *(int *) qdst = packed; if ((lane & 7) == 0) *ddst = __half2float(__float2half_rn(dd)); }
 }
-template <int T, int NW> __device__ __forceinline__ void quant_q80_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d) {
-    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+template <int T, int NW> __device__ __forceinline__ void quant_q80_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, int ubeg, int ustr) {
+    const int lane = threadIdx.x % WAVE;
     const int nch = (k + 255) / 256, nb = k / 32, nu = T*nch;       // a chunk = 256 elements = 8 blocks of 32 (last one may be ragged)
     constexpr int PB = 4;
-    for (int u0 = wave; u0 < nu; u0 += NW*PB) {
+    for (int u0 = ubeg; u0 < nu; u0 += ustr*PB) {
         float4 vv[PB];
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int u = u0 + p*NW; vv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int u = u0 + p*ustr; vv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (u < nu) { const int t = u / nch, ch = u - t*nch, e = ch*256 + lane*4; if (e < k) vv[p] = fetch4(a, sc, t, e); }
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const int u = u0 + p*NW;
+            const int u = u0 + p*ustr;
             if (u >= nu) break;
             const int t = u / nch, ch = u - t*nch, e = ch*256 + lane*4;
             q80_unit(vv[p], q + t*k + e, d + t*nb + e/32, lane, e < k);
@@ -209,8 +212,8 @@ template <> struct wfrag<GGML_TYPE_Q4_K> {
         const i32x4 q = qs; qs = q & 0x0F0F0F0F; hdr = (q >> 4) & 0x0F0F0F0F;                         // qs = low nibbles, hdr = high nibbles from here on
     }
     __device__ __forceinline__ float mac(const act_regs & a) const {
-        const int si = sc0*dot16(qs, a.lo) + sc1*dot16(hdr, a.hi);
-        const int mi = m0*a.b0 + m1*a.b1;
+        const int si = __mul24(sc0, dot16(qs, a.lo)) + __mul24(sc1, dot16(hdr, a.hi));   // 6-bit x 23-bit: full-rate 24-bit multiply
+        const int mi = __mul24(m0, a.b0) + __mul24(m1, a.b1);
         return (dw*a.dy)*(float) si - (mw*a.dy)*(float) mi;
     }
 };
@@ -236,8 +239,8 @@ template <> struct wfrag<GGML_TYPE_Q5_K> {
         hdr = ((q >> 4) & 0x0F0F0F0F) | (((hb >> (2*g + 1)) & 0x01010101) << 4);
     }
     __device__ __forceinline__ float mac(const act_regs & a) const {
-        const int si = sc0*dot16(qs, a.lo) + sc1*dot16(hdr, a.hi);
-        const int mi = m0*a.b0 + m1*a.b1;
+        const int si = __mul24(sc0, dot16(qs, a.lo)) + __mul24(sc1, dot16(hdr, a.hi));   // 6-bit x 23-bit: full-rate 24-bit multiply
+        const int mi = __mul24(m0, a.b0) + __mul24(m1, a.b1);
         return (dw*a.dy)*(float) si - (mw*a.dy)*(float) mi;
     }
 };
@@ -265,7 +268,7 @@ template <> struct wfrag<GGML_TYPE_Q6_K> {
         if (!valid) dw = 0.f;
     }
     __device__ __forceinline__ float mac(const act_regs & a) const {
-        const int si = sc0*(dot16(ql, a.lo) - 32*a.b0) + sc1*(dot16(qh, a.hi) - 32*a.b1);
+        const int si = __mul24(sc0, dot16(ql, a.lo) - 32*a.b0) + __mul24(sc1, dot16(qh, a.hi) - 32*a.b1);
         return (dw*a.dy)*(float) si;
     }
 };
@@ -323,7 +326,7 @@ template <int TYPE> struct act_kind { static constexpr bool K = (TYPE == GGML_TY
 // weight rows per wave per pass: 2 (RoPE pairs live in one wave); 1 in DUAL mode, where a wave already carries two matrices
 template <bool DUAL> struct rows_per_wave { static constexpr int R = DUAL ? 1 : 2; };
 
-template <int TYPE, int T, int NW, bool DUAL>
+template <int TYPE, int T, int NW, bool DUAL, bool PRE>
 __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool KQ = act_kind<TYPE>::K;
@@ -368,9 +371,15 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
     wfrag<TYPE> fa[NF], fb[NF];
     int g = blockIdx.x*NW + wave, mi = 0, row0 = 0;
     if (g < total) { set_rows(g, mi, row0); load_step(fa, 0); }          // in flight across the prologue
-    if (L.act.norm) row_scales<T, NW>(L.act, k, sc, red);
-    if (KQ) quant_q8K_to_lds<T, NW>(L.act, sc, k, lq, ld, lb);
-    else    quant_q80_to_lds<T, NW>(L.act, sc, k, lq, ld);
+    if (PRE) {                      // activations were quantised once by k_quant_act: copy the image (same layout) into LDS
+        const int n16 = (int)((act_img_bytes(KQ, T, k) + 15) / 16);
+        const i32x4 * src = (const i32x4 *) L.act.pre; i32x4 * dst = (i32x4 *) smem;
+        for (int i = threadIdx.x; i < n16; i += NW*WAVE) dst[i] = src[i];
+    } else {
+        if (L.act.norm) row_scales<T, NW>(L.act, k, sc, red);
+        if (KQ) quant_q8K_to_lds<T, NW>(L.act, sc, k, lq, ld, lb, wave, NW);
+        else    quant_q80_to_lds<T, NW>(L.act, sc, k, lq, ld, wave, NW);
+    }
     __syncthreads();
 
     while (g < total) {
@@ -473,6 +482,35 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
     }
 }
 
+// Quantise-once: the same prologue as a stand-alone kernel writing the LDS image to HBM scratch; used when the
+// image is big (T*k) so that 512 blocks do not each redo it.  Blocks share the units round-robin.
+template <bool KQ, int T, int NW>
+__global__ void __launch_bounds__(NW*WAVE) k_quant_act(const act_src a, int k, char * out) {
+    __shared__ double red[NW*T];
+    __shared__ float  sc[T];
+    if (a.norm) row_scales<T, NW>(a, k, sc, red);
+    int8_t * q = (int8_t *) out;
+    float  * d = (float *)(out + T*k);
+    short  * bs = (short *)((char *) d + T*(KQ ? k/256 : k/32)*4);
+    const int wave = threadIdx.x / WAVE;
+    if (KQ) quant_q8K_to_lds<T, NW>(a, sc, k, q, d, bs, blockIdx.x*NW + wave, gridDim.x*NW);
+    else    quant_q80_to_lds<T, NW>(a, sc, k, q, d, blockIdx.x*NW + wave, gridDim.x*NW);
+}
+template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src & a, int k, char * out) {
+    const int units = T * ((k + 255) / 256);
+    int grid = (units + 8*2 - 1) / (8*2); if (grid > 64) grid = 64; if (grid < 1) grid = 1;
+    switch (T) {
+#define QA(n) case n: k_quant_act<KQ, n, 8><<<grid, 512, 0, st>>>(a, k, out); break;
+        QA(1) QA(2) QA(3) QA(4) QA(5) QA(6) QA(7) QA(8)
+#undef QA
+        default: MI_ABORT("quant_act: T=%d", T);
+    }
+}
+size_t mi_act_image_bytes(int type, int T, int k) { return (act_img_bytes(mi_traits(type).blck == 256, T, k) + 255) & ~(size_t) 255; }
+void mi_quant_act(hipStream_t st, int type, int T, const act_src & a, int k, char * out) {
+    if (mi_traits(type).blck == 256) quant_act_T<true>(st, T, a, k, out); else quant_act_T<false>(st, T, a, k, out);
+}
+
 // ---------------------------------------------------------------- host side
 static std::mutex g_attr_mu;
 static std::unordered_set<const void *> g_attr_done;
@@ -516,7 +554,7 @@ static double launch_bytes(const mmvq_launch & L, int T, bool dual) {
 
 static inline size_t lds_total(bool ktype, int T, int k, int NW) { return act_lds_bytes(ktype, T, k) + 8 + (size_t) NW*T*8 + (size_t) T*4 + 16; }
 
-template <int TYPE, int T, int NW, bool DUAL>
+template <int TYPE, int T, int NW, bool DUAL, bool PRE>
 static void launch_one(hipStream_t st, const mmvq_launch & L) {
     const size_t lds = lds_total(act_kind<TYPE>::K, T, L.k, NW);
     MI_ASSERT(lds <= 160*1024);
@@ -533,7 +571,7 @@ static void launch_one(hipStream_t st, const mmvq_launch & L) {
     const int cap = 256 * blocks_cu;
     if (grid > cap) grid = cap;
     if (grid < 1) return;
-    auto fn = k_mmvq<TYPE, T, NW, DUAL>;
+    auto fn = k_mmvq<TYPE, T, NW, DUAL, PRE>;
     ensure_lds_attr((const void *) fn, lds);
     if (g_prof_on) {
         prof_rec r; HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b)); r.bytes = launch_bytes(L, T, DUAL);
@@ -546,8 +584,8 @@ static void launch_one(hipStream_t st, const mmvq_launch & L) {
     fn<<<grid, NW*WAVE, lds, st>>>(L);
 }
 template <int TYPE, int T> static void launch_T(hipStream_t st, const mmvq_launch & L) {
-    if (L.swiglu) launch_one<TYPE, T, 8, true >(st, L);
-    else          launch_one<TYPE, T, 8, false>(st, L);
+    if (L.act.pre) { if (L.swiglu) launch_one<TYPE, T, 8, true, true >(st, L); else launch_one<TYPE, T, 8, false, true >(st, L); }
+    else           { if (L.swiglu) launch_one<TYPE, T, 8, true, false>(st, L); else launch_one<TYPE, T, 8, false, false>(st, L); }
 }
 template <int TYPE> static void launch_type(hipStream_t st, int T, const mmvq_launch & L) {
     switch (T) {
@@ -570,15 +608,31 @@ int mi_mmvq_max_tokens(int type, int k) {
 }
 
 // Runs one (possibly multi-matrix) product over Ttot tokens, at most mi_mmvq_max_tokens() per launch.
-void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0) {
+// Activation images big enough to be worth quantising once (instead of in every block's prologue) go through a small
+// ring of HBM scratch slots; entries are keyed by the ggml tensor that owns the activations (unique per graph_compute
+// epoch), so wq|wk and a differently-typed wv, or gate|up launched separately, share one image.
+static const int PRE_MIN_ELEMS = 8192;      // T*k above this: quantise once
+void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_act_cache * cache, const void * key) {
     const int tmax = mi_mmvq_max_tokens(type, L0.k);
     MI_ASSERT(tmax >= 1);
+    const int kq = mi_traits(type).blck == 256;
     for (int t0 = 0; t0 < Ttot; t0 += tmax) {
         const int T = (Ttot - t0) < tmax ? (Ttot - t0) : tmax;
         mmvq_launch L = L0;
         L.act.X += (size_t) t0 * L.act.xs;
+        L.act.pre = nullptr;
         for (int i = 0; i < L.n_mat; ++i) { L.m[i].out += (size_t) t0 * L.m[i].o_tok; if (L.m[i].res) L.m[i].res += (size_t) t0 * L.m[i].r_tok; }
         if (L.rope.pos) L.rope.pos += t0;
+        if (cache && cache->pool && (int64_t) T * L.k > PRE_MIN_ELEMS && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes) {
+            int hit = -1;
+            if (key) for (int i = 0; i < MI_ACT_SLOTS; ++i) { const auto & e = cache->e[i]; if (e.key == key && e.epoch == cache->epoch && e.t0 == t0 && e.T == T && e.kq == kq && e.k == L.k) { hit = i; break; } }
+            if (hit < 0) {
+                hit = cache->next; cache->next = (cache->next + 1) % MI_ACT_SLOTS;
+                mi_quant_act(st, type, T, L.act, L.k, cache->pool + (size_t) hit * cache->slot_bytes);
+                cache->e[hit] = { key, cache->epoch, t0, T, kq, L.k };
+            }
+            L.act.pre = cache->pool + (size_t) hit * cache->slot_bytes;
+        }
         switch (type) {
             case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, T, L); break;
             case GGML_TYPE_Q5_K: launch_type<GGML_TYPE_Q5_K>(st, T, L); break;
@@ -591,7 +645,7 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0) {
 }
 
 // dst[rows, T, b2, b3] = W[k, rows, b2/r2, b3/r3] . X[k, T, b2, b3]   (+ residual)
-void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out) {
+void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out, mi_act_cache * cache) {
     const ggml_tensor * w = dst->src[0], * x = dst->src[1];
     const int k = (int) w->ne[0], rows = (int) w->ne[1];
     const int64_t Ttot = x->ne[1];
@@ -605,6 +659,6 @@ void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor 
         L.m[0].W = (const char *) w->data + (i2/r2)*w->nb[2] + (i3/r3)*w->nb[3]; L.m[0].row_bytes = w->nb[1]; L.m[0].rows = rows;
         L.m[0].epi = EPI_F32; L.m[0].out = (char *) out->data + i2*out->nb[2] + i3*out->nb[3]; L.m[0].o_row = 4; L.m[0].o_tok = out->nb[1];
         if (residual) { L.m[0].res = (const float *)((const char *) residual->data + i2*residual->nb[2] + i3*residual->nb[3]); L.m[0].r_tok = residual->nb[1]/4; }
-        mi_mmvq_run(st, w->type, (int) Ttot, L);
+        mi_mmvq_run(st, w->type, (int) Ttot, L, cache, (x->ne[2] == 1 && x->ne[3] == 1) ? (const void *) x : nullptr);
     }
 }

@@ -89,6 +89,7 @@ struct mi_backend_ctx {           // ggml_backend::context  (one HIP stream)
     hipStream_t  stream;
     void *       scratch;         // device scratch (activation quantisation etc.)
     size_t       scratch_size;
+    struct mi_act_cache * act_cache;   // kernels.h
     char         name[32];
 };
 struct mi_buffer_ctx {            // ggml_backend_buffer::context
