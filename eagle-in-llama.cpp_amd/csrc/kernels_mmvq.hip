@@ -368,9 +368,35 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
         for (int i = 0; i < NF; ++i) f[i].load(rp[i], unit, lane, k);
     };
 
-    wfrag<TYPE> fa[NF], fb[NF];
+    // Two register stages of S k-steps each: while stage A is being consumed the loads of stage B are in flight
+    // (2*S*NF 16-byte loads per lane outstanding: the bytes-in-flight that an HBM-bound stream needs at 8-16 waves/CU).
+    constexpr int S = 2;
+    wfrag<TYPE> fa[S][NF], fb[S][NF];
+    auto load_stage = [&](wfrag<TYPE> (*f)[NF], int s0) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) if (s0 + u < nsteps) load_step(f[u], s0 + u);
+    };
+    auto consume = [&](wfrag<TYPE> (*f)[NF], int s0, float (*acc)[T]) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+            if (s0 + u >= nsteps) break;
+            const int unit = (s0 + u)*8 + sub; const bool valid = wfrag<TYPE>::valid(unit, lane, k); const int uc = min(unit, nunits - 1);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) f[u][i].decode(lane, valid);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                act_regs a;
+                const int8_t * aq = lq + t*k + uc*(KQ ? 256 : (TYPE == GGML_TYPE_Q8_0 ? 128 : 256));
+                a.lo = *(const i32x4 *)(aq + alo); a.hi = *(const i32x4 *)(aq + ahi);
+                if (KQ) { const short * bp = lb + t*(k/16) + uc*16; a.b0 = bp[blo]; a.b1 = bp[bhi]; a.dy = ld[t*(k/256) + uc]; }
+                else    { a.b0 = a.b1 = 0; a.dy = ld[t*(k/32) + uc*(TYPE == GGML_TYPE_Q8_0 ? 4 : 8) + blo]; }
+#pragma unroll
+                for (int i = 0; i < NF; ++i) acc[i][t] += f[u][i].mac(a);
+            }
+        }
+    };
     int g = blockIdx.x*NW + wave, mi = 0, row0 = 0;
-    if (g < total) { set_rows(g, mi, row0); load_step(fa, 0); }          // in flight across the prologue
+    if (g < total) { set_rows(g, mi, row0); load_stage(fa, 0); }         // in flight across the prologue
     if (PRE) {                      // activations were quantised once by k_quant_act: copy the image (same layout) into LDS
         const int n16 = (int)((act_img_bytes(KQ, T, k) + 15) / 16);
         const i32x4 * src = (const i32x4 *) L.act.pre; i32x4 * dst = (i32x4 *) smem;
@@ -390,48 +416,17 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[i][t] = 0.f;
         const int gn = g + gstride;
-        for (int s = 0; s < nsteps; s += 2) {
-            // ---- even step: fa holds step s; prefetch step s+1 (or the next group's step 0) into fb
-            const bool more1 = s + 1 < nsteps;
-            if (more1) load_step(fb, s + 1);
-            {
-                const int unit = s*8 + sub; const bool valid = wfrag<TYPE>::valid(unit, lane, k); const int uc = min(unit, nunits - 1);
-#pragma unroll
-                for (int i = 0; i < NF; ++i) fa[i].decode(lane, valid);
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    act_regs a;
-                    const int8_t * aq = lq + t*k + uc*(KQ ? 256 : (TYPE == GGML_TYPE_Q8_0 ? 128 : 256));
-                    a.lo = *(const i32x4 *)(aq + alo); a.hi = *(const i32x4 *)(aq + ahi);
-                    if (KQ) { const short * bp = lb + t*(k/16) + uc*16; a.b0 = bp[blo]; a.b1 = bp[bhi]; a.dy = ld[t*(k/256) + uc]; }
-                    else    { a.b0 = a.b1 = 0; a.dy = ld[t*(k/32) + uc*(TYPE == GGML_TYPE_Q8_0 ? 4 : 8) + blo]; }
-#pragma unroll
-                    for (int i = 0; i < NF; ++i) acc[i][t] += fa[i].mac(a);
-                }
-            }
-            if (!more1) break;
-            // ---- odd step: fb holds step s+1; prefetch step s+2 into fa
-            if (s + 2 < nsteps) load_step(fa, s + 2);
-            {
-                const int unit = (s + 1)*8 + sub; const bool valid = wfrag<TYPE>::valid(unit, lane, k); const int uc = min(unit, nunits - 1);
-#pragma unroll
-                for (int i = 0; i < NF; ++i) fb[i].decode(lane, valid);
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    act_regs a;
-                    const int8_t * aq = lq + t*k + uc*(KQ ? 256 : (TYPE == GGML_TYPE_Q8_0 ? 128 : 256));
-                    a.lo = *(const i32x4 *)(aq + alo); a.hi = *(const i32x4 *)(aq + ahi);
-                    if (KQ) { const short * bp = lb + t*(k/16) + uc*16; a.b0 = bp[blo]; a.b1 = bp[bhi]; a.dy = ld[t*(k/256) + uc]; }
-                    else    { a.b0 = a.b1 = 0; a.dy = ld[t*(k/32) + uc*(TYPE == GGML_TYPE_Q8_0 ? 4 : 8) + blo]; }
-#pragma unroll
-                    for (int i = 0; i < NF; ++i) acc[i][t] += fb[i].mac(a);
-                }
-            }
+        for (int s = 0; s < nsteps; s += 2*S) {
+            if (s + S < nsteps) load_stage(fb, s + S);
+            consume(fa, s, acc);
+            if (s + S >= nsteps) break;
+            if (s + 2*S < nsteps) load_stage(fa, s + 2*S);
+            consume(fb, s + S, acc);
         }
         // ---- next group's first loads go out before this group's reduction/epilogue
         const int cur_row0 = row0;
         int nmi = mi, nrow0 = row0;
-        if (gn < total) { set_rows(gn, nmi, nrow0); load_step(fa, 0); }
+        if (gn < total) { set_rows(gn, nmi, nrow0); load_stage(fa, 0); }
         // ---- reduce: every lane ends up with every sum
 #pragma unroll
         for (int i = 0; i < NF; ++i)
