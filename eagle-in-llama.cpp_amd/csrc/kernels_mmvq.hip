@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
 
     // Two register stages of S k-steps each: while stage A is being consumed the loads of stage B are in flight
     // (2*S*NF 16-byte loads per lane outstanding: the bytes-in-flight that an HBM-bound stream needs at 8-16 waves/CU).
-    constexpr int S = 2;
+    constexpr int S = (TYPE == GGML_TYPE_Q6_K || TYPE == GGML_TYPE_Q5_K) ? 1 : 2;      // wider fragments: keep the register budget for occupancy
     wfrag<TYPE> fa[S][NF], fb[S][NF];
     auto load_stage = [&](wfrag<TYPE> (*f)[NF], int s0) {
 #pragma unroll
