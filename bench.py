@@ -92,7 +92,7 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("EH_FORCE_TP"):      # EH_FORCE_TP=1: rehearse the TP path with a 1-rank communicator
         from bench_tp import main_tp           # one process per GPU, row-split tensor parallel over RCCL
         return main_tp(args, rank, world, local)
 

@@ -1,0 +1,119 @@
+"""bench_tp.py -- the N > 1 leg of bench.py: row-split tensor parallelism, one process per GPU, RCCL over xGMI.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Sharding (SURVEY.md 8e / DESIGN.md 6): every rank holds a slice of the SAME global synthetic Vicuna-7B tensors --
+wq/wk/wv/gate/up by output rows (heads), wo/ffn_down by k in whole 256-element super-blocks -- keeps its own heads' KV,
+and the layer needs two all-reduces of [n_embd, T] fp32, enqueued by the host on the plugin's HIP stream between graph
+segments (host/model.cpp cut points, host/tp.cpp).  The EAGLE head and the LM head stay on rank 0: rank 0 drafts, the
+draft tokens are broadcast (8 ints, gloo), all ranks verify together, rank 0 accepts and broadcasts the count.
+Total work is fixed as N grows => "scaling": "strong".  The same code path runs on CPU with gloo in
+tests/test_tp_gloo.py (world_size 2) and, with EH_FORCE_TP=1, on one GPU with a 1-rank RCCL communicator.
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+N_DRAFT = 5
+
+
+def main_tp(args, rank, world, local):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from bench import load_pkg, prompt_tokens, PROMPT_LEN
+
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    ctl = dist.new_group(backend="gloo")                    # small host-side control messages (token ids)
+    ea = load_pkg()
+    h = ea._model_sigs()
+    be = ea.Backend.mi355x(local)
+
+    idbuf = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        raw = C.create_string_buffer(128)
+        assert h.eh_tp_unique_id(raw) == 0, "librccl not loadable"
+        idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+    dist.broadcast(idbuf, 0, group=ctl)
+    comm = h.eh_tp_init(be.h, bytes(idbuf.numpy().tobytes()), rank, world)
+    assert comm, "ncclCommInitRank failed"
+
+    tgt = ea.Model(be, args.config, args.ftype, n_ctx=2048, seed=42, tp_rank=rank, tp_size=world)
+    h.eh_tp_bind(comm, tgt.h)
+    dft = ea.Model(be, args.config, args.ftype, n_ctx=2048, eagle_of=tgt, seed=42, accept_p=args.accept_p) if rank == 0 else None
+    prompt = prompt_tokens(1234)
+
+    def sync():
+        torch.cuda.synchronize()
+        dist.barrier()
+
+    # ---- prompt (all ranks decode it; rank 0 also primes the draft) -------------------------------------------------
+    sess = None
+    if rank == 0:
+        pr = (C.c_int32 * len(prompt))(*prompt)
+    # followers mirror rank 0's target calls one for one: prompt decode with all outputs
+    if rank == 0:
+        sess = h.eh_spec_begin(tgt.h, dft.h, pr, len(prompt))
+        assert sess
+    else:
+        tgt.kv_clear()
+        tgt.decode(prompt, list(range(len(prompt))), want_hidden=True)
+    n_past = len(prompt)
+    st = (C.c_double * 16)()
+    out = (C.c_int32 * (N_DRAFT + 2))()
+    drafts = (C.c_int32 * (N_DRAFT + 2))()
+    msg = torch.zeros(N_DRAFT + 4, dtype=torch.int32)
+
+    def one_round():
+        nonlocal n_past
+        if rank == 0:
+            nd = h.eh_spec_draft(sess, N_DRAFT, 0.0, drafts, st)
+            npast = C.c_int32(); idl = C.c_int32(); h.eh_spec_state(sess, C.byref(npast), C.byref(idl))
+            msg[0] = nd; msg[1] = idl.value; msg[2] = npast.value
+            for i in range(nd):
+                msg[3 + i] = drafts[i]
+        dist.broadcast(msg, 0, group=ctl)
+        nd, idl, npast = int(msg[0]), int(msg[1]), int(msg[2])
+        if rank == 0:
+            n_out = h.eh_spec_verify(sess, out, st)
+            msg[0] = n_out
+        else:
+            toks = [idl] + [int(msg[3 + i]) for i in range(nd)]
+            tgt.decode(toks, [npast + i for i in range(nd + 1)], want_hidden=True)
+        dist.broadcast(msg[:1], 0, group=ctl)
+        n_out = int(msg[0])
+        n_past = npast + n_out                      # id_last + accepted drafts stay in the cache
+        if rank != 0:
+            tgt.kv_seq_rm(0, n_past, -1)
+        return n_out
+
+    for _ in range(args.warmup):
+        one_round()
+    for i in range(16):
+        st[i] = 0.0
+    sync()
+    t0 = time.perf_counter()
+    n_tok = 0
+    for _ in range(args.steps):
+        n_tok += one_round()
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=ctl)
+    dt = float(tmax[0])
+    if rank == 0:
+        res = {"metric": "accepted tokens/sec + accept-rate, Vicuna-7B Q4_K_M + EAGLE, 1/8 GPU", "value": round(n_tok / dt, 2), "unit": "tokens/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 (dp4a) -> f32", "data": "synthetic",
+               "config": {"workload": f"{args.config} {args.ftype} target row-split TP={world} (2 RCCL all-reduces/layer) + EAGLE head on rank 0, depth {N_DRAFT}, "
+                                      f"{PROMPT_LEN}-token synthetic prompt, greedy", "n_draft": N_DRAFT, "accept_p_synthetic": args.accept_p},
+               "accept_rate": round(st[2] / max(1.0, st[1]), 4), "tokens_per_round": round(n_tok / args.steps, 3),
+               "shard_weight_bytes": tgt.weight_bytes, "allreduces": tgt.n_allreduce}
+        print(json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()

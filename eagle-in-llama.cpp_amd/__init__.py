@@ -252,6 +252,9 @@ CONFIGS = {
 }
 
 
+ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64)
+
+
 def _model_sigs():
     h = host()
     if getattr(h, "_model_sigs_done", False):
@@ -260,7 +263,8 @@ def _model_sigs():
     i32p = C.POINTER(C.c_int32)
     sig = {
         "eh_model_create": (vp, [vp, i32p, f32, f32, C.c_uint64, f32, i32, vp]),
-        "eh_model_free": (None, [vp]), "eh_model_weight_bytes": (i64, [vp]), "eh_model_n_nodes": (i32, [vp]),
+        "eh_model_free": (None, [vp]), "eh_model_set_allreduce": (None, [vp, ALLREDUCE_CB, vp]), "eh_model_n_allreduce": (i64, [vp]),
+        "eh_tp_unique_id": (i32, [C.c_char_p]), "eh_tp_init": (vp, [vp, C.c_char_p, i32, i32]), "eh_tp_bind": (None, [vp, vp]), "eh_tp_free": (None, [vp]), "eh_model_weight_bytes": (i64, [vp]), "eh_model_n_nodes": (i32, [vp]),
         "eh_model_decode": (i32, [vp, i32, i32p, i32p, i32p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), i32]),
         "eh_model_n_outputs": (i32, [vp]), "eh_model_logits": (C.POINTER(C.c_float), [vp]), "eh_model_hidden": (C.POINTER(C.c_float), [vp]),
         "eh_model_kv_clear": (None, [vp]), "eh_model_kv_seq_rm": (None, [vp, i32, i32, i32]),
@@ -269,6 +273,7 @@ def _model_sigs():
         "eh_spec_run": (i32, [vp, vp, i32p, i32, i32, i32, f32, i32p, f64p]),
         "eh_spec_begin": (vp, [vp, vp, i32p, i32]), "eh_spec_rounds": (i32, [vp, i32, i32, f32, i32p, i32, f64p]), "eh_spec_end": (None, [vp]),
         "eh_plain_run": (i32, [vp, i32p, i32, i32, i32p, f64p]),
+        "eh_spec_draft": (i32, [vp, i32, f32, i32p, f64p]), "eh_spec_verify": (i32, [vp, i32p, f64p]), "eh_spec_state": (None, [vp, i32p, i32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(h, name)
@@ -281,13 +286,14 @@ class Model:
     """Synthetic llama (target) or EAGLE head (draft) with the reference's tensor shapes and quantisation mix."""
 
     def __init__(self, backend, config="vicuna-7b", ftype="q4_k_m", n_ctx=2048, eagle_of=None, seed=42, accept_p=0.8,
-                 predictable=True, rms_eps=1e-6, rope_base=10000.0):
+                 predictable=True, rms_eps=1e-6, rope_base=10000.0, tp_rank=0, tp_size=1):
         h = _model_sigs()
         dims = list(CONFIGS[config]) if isinstance(config, str) else list(config)
         if eagle_of is not None:
             dims[5] = 1
-        ci = (C.c_int32 * 10)(*dims, n_ctx, FTYPE[ftype], 1 if eagle_of is not None else 0)
+        ci = (C.c_int32 * 12)(*dims, n_ctx, FTYPE[ftype], 1 if eagle_of is not None else 0, tp_rank, tp_size)
         self.be, self.dims, self.n_ctx, self.ftype = backend, dims, n_ctx, ftype
+        self.tp_rank, self.tp_size = tp_rank, tp_size
         self.n_embd, self.n_vocab = dims[0], dims[6]
         self.target = eagle_of
         self.h = h.eh_model_create(backend.h, ci, rms_eps, rope_base, seed, accept_p, 1 if predictable else 0, eagle_of.h if eagle_of else None)
@@ -298,6 +304,15 @@ class Model:
         if self.h:
             _model_sigs().eh_model_free(self.h)
             self.h = None
+
+    def set_allreduce(self, fn):
+        """fn(ptr:int, n_floats:int) sums the fp32 buffer at `ptr` over all ranks in place (CPU/gloo tests)."""
+        self._ar = ALLREDUCE_CB(lambda user, data, n: fn(data, n))
+        _model_sigs().eh_model_set_allreduce(self.h, self._ar, None)
+
+    @property
+    def n_allreduce(self):
+        return _model_sigs().eh_model_n_allreduce(self.h)
 
     @property
     def weight_bytes(self):
@@ -320,6 +335,8 @@ class Model:
         if rc != 0:
             raise RuntimeError(f"decode returned {rc}")
         no = h.eh_model_n_outputs(self.h)
+        if self.tp_size > 1 and self.tp_rank != 0:
+            return None, None                    # tensor parallel: the LM head and the hidden-state channel live on rank 0
         lgs = np.ctypeslib.as_array(h.eh_model_logits(self.h), (no, self.n_vocab)).copy()
         hid = np.ctypeslib.as_array(h.eh_model_hidden(self.h), (no, self.n_embd)).copy() if want_hidden else None
         return lgs, hid

@@ -268,7 +268,10 @@ static ggml_backend_feature * reg_get_features(ggml_backend_reg_t) { return g_fe
 // row-split weights: implemented in split.cpp (tensor-parallel over the visible devices)
 extern "C" ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device, const float * tensor_split);
 
+// extension for hosts that interleave their own stream work (RCCL collectives between graph segments)
+static void * backend_stream(ggml_backend_t b) { return be_is_ours(b) ? (void *) ((mi_backend_ctx *) b->context)->stream : nullptr; }
 static void * reg_proc(ggml_backend_reg_t, const char * name) {
+    if (!strcmp(name, "ggml_backend_mi355x_stream"))     return (void *) backend_stream;
     if (!strcmp(name, "ggml_backend_get_features"))      return (void *) reg_get_features;
     if (!strcmp(name, "ggml_backend_split_buffer_type")) return (void *) ggml_backend_mi355x_split_buffer_type;
     return nullptr;

@@ -61,8 +61,8 @@ static int spec_prompt(SpecState & s, const int32_t * prompt, int n) {
     return 0;
 }
 
-// one speculative round; returns number of new tokens appended to out (>= 1) or < 0 on error
-static int spec_round(SpecState & s, int n_draft, float p_min, int32_t * out, double * st) {
+// draft phase of a round (runs where the EAGLE head lives: rank 0 under tensor parallelism)
+static int spec_draft(SpecState & s, int n_draft, float p_min, double * st) {
     Model & T = *s.tgt, & D = *s.dft;
     const int E = T.cfg.n_embd, V = T.cfg.n_vocab;
     const double t0 = now_us();
@@ -89,6 +89,13 @@ static int spec_round(SpecState & s, int n_draft, float p_min, int32_t * out, do
         std::vector<float> feat(g, g + E);
         d.clear(); d.add(id, pos, 0, true); d.hidd = std::move(feat);
     }
+    st[ST_T_DRAFT_US] += now_us() - t0;
+    return (int) s.drafts.size();
+}
+// verify + accept + bookkeeping of a round; returns number of new tokens appended to out (>= 1) or < 0 on error
+static int spec_verify(SpecState & s, int32_t * out, double * st) {
+    Model & T = *s.tgt;
+    const int E = T.cfg.n_embd, V = T.cfg.n_vocab;
     const double t1 = now_us();
     // ---- verify: [id_last, drafts...] in one target batch, logits for every token
     Batch & b = s.bt; b.clear();
@@ -114,19 +121,26 @@ static int spec_round(SpecState & s, int n_draft, float p_min, int32_t * out, do
     s.n_past += m + 1;
     T.kv.seq_rm(0, s.n_past, -1);
     s.id_last = out[n_out - 1];
-    const double t2 = now_us();
-    st[ST_T_DRAFT_US] += t1 - t0; st[ST_T_VERIFY_US] += t2 - t1;
+    st[ST_T_VERIFY_US] += now_us() - t1;
     return n_out;
+}
+static int spec_round(SpecState & s, int n_draft, float p_min, int32_t * out, double * st) {
+    const int nd = spec_draft(s, n_draft, p_min, st);
+    if (nd < 0) return nd;
+    return spec_verify(s, out, st);
 }
 
 EH_API void * eh_model_create(void * backend, const int * ci, float rms_eps, float rope_base, uint64_t seed, float accept_p, int predictable, void * target) {
     ModelConfig c;
     c.n_embd = ci[0]; c.n_head = ci[1]; c.n_head_kv = ci[2]; c.head_dim = ci[3]; c.n_ff = ci[4]; c.n_layer = ci[5]; c.n_vocab = ci[6];
     c.n_ctx = ci[7]; c.ftype = ci[8]; c.eagle = ci[9] != 0; c.rms_eps = rms_eps; c.rope_base = rope_base;
+    c.tp_rank = ci[10]; c.tp_size = ci[11] > 0 ? ci[11] : 1;
     SynthOptions o; o.seed = seed; o.accept_p = accept_p; o.predictable = predictable != 0;
     return Model::create_synthetic((mh::Backend *) backend, c, o, (const Model *) target);
 }
 EH_API void eh_model_free(void * m) { delete (Model *) m; }
+EH_API void eh_model_set_allreduce(void * m, Model::allreduce_fn fn, void * user) { ((Model *) m)->allreduce = fn; ((Model *) m)->allreduce_user = user; }
+EH_API int64_t eh_model_n_allreduce(void * m) { return ((Model *) m)->n_allreduce; }
 EH_API int64_t eh_model_weight_bytes(void * m) { return (int64_t) ((Model *) m)->weight_bytes; }
 EH_API int eh_model_n_nodes(void * m) { return ((Model *) m)->last_n_nodes; }
 EH_API int eh_model_decode(void * mp, int n, const int32_t * tok, const int32_t * pos, const int32_t * seq, const uint8_t * lg, const float * hidd, int want_hidden) {
@@ -189,6 +203,15 @@ EH_API int eh_spec_rounds(void * sp, int rounds, int n_draft, float p_min, int32
     return n;
 }
 EH_API void eh_spec_end(void * sp) { delete (SpecSession *) sp; }
+// the two halves of a round, for launchers that synchronise ranks in between (tensor parallel: bench_tp.py)
+EH_API int eh_spec_draft(void * sp, int n_draft, float p_min, int32_t * drafts, double * stats) {
+    SpecSession * ss = (SpecSession *) sp;
+    const int n = spec_draft(ss->s, n_draft, p_min, stats);
+    for (int i = 0; i < n; ++i) drafts[i] = ss->s.drafts[i];
+    return n;
+}
+EH_API int eh_spec_verify(void * sp, int32_t * out_tokens, double * stats) { SpecSession * ss = (SpecSession *) sp; return spec_verify(ss->s, out_tokens, stats); }
+EH_API void eh_spec_state(void * sp, int32_t * n_past, int32_t * id_last) { SpecSession * ss = (SpecSession *) sp; *n_past = ss->s.n_past; *id_last = ss->s.id_last; }
 
 // Plain autoregressive decoding (what the speculative path must beat by >= 2x)
 EH_API int eh_plain_run(void * tgt, const int32_t * prompt, int n_prompt, int n_predict, int32_t * out_tokens, double * stats) {

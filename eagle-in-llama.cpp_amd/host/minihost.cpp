@@ -227,6 +227,14 @@ enum ggml_status Ctx::compute_async() {
     graph.nodes = node_array.data(); graph.order = GGML_CGRAPH_EVAL_ORDER_LEFT_TO_RIGHT;
     return be->be->iface.graph_compute(be->be, &graph);
 }
+enum ggml_status Ctx::compute_range(int n0, int n1) {
+    if (n1 <= n0) return GGML_STATUS_SUCCESS;
+    node_array.assign(nodes.begin() + n0, nodes.begin() + n1);
+    memset(&graph, 0, sizeof(graph));
+    graph.size = (int) node_array.size(); graph.n_nodes = (int) node_array.size(); graph.n_leafs = 0;
+    graph.nodes = node_array.data(); graph.order = GGML_CGRAPH_EVAL_ORDER_LEFT_TO_RIGHT;
+    return be->be->iface.graph_compute(be->be, &graph);
+}
 enum ggml_status Ctx::compute() {
     const auto t0 = std::chrono::steady_clock::now();
     enum ggml_status s = compute_async();

@@ -91,6 +91,7 @@ struct Ctx {
     void get(const ggml_tensor * t, void * data, size_t offset, size_t size);
     enum ggml_status compute();                  // graph_compute over `nodes` + synchronize
     enum ggml_status compute_async();
+    enum ggml_status compute_range(int n0, int n1);   // nodes [n0, n1) only, asynchronous (tensor-parallel segments)
     double t_issue_us = 0, t_wait_us = 0;        // host time inside graph_compute vs waiting for the device
 
   private:

@@ -184,36 +184,49 @@ Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const
     m->wctx.reset(new mh::Ctx(be)); m->wctx->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
     m->gctx.reset(new mh::Ctx(be)); m->gctx->usage = GGML_BACKEND_BUFFER_USAGE_COMPUTE;
     mh::Ctx & w = *m->wctx;
-    const int E = cfg.n_embd, KV = cfg.n_head_kv * cfg.head_dim, Q = cfg.n_head * cfg.head_dim, F = cfg.n_ff, V = cfg.n_vocab;
-    struct Pending { ggml_tensor * t; int kind; uint64_t seed; float scale; };   // kind 0 random blocks, 1 ones(f32), 2 zeros(f32), 3 identity
+    // tensor-parallel shard (Megatron pairing on quantised blocks): heads split evenly, n_ff split in whole 256-element
+    // super-blocks so that the k-split of ffn_down stays block-aligned
+    const int N = cfg.tp_size, R = cfg.tp_rank;
+    if (cfg.n_head % N || cfg.n_head_kv % N) { delete m; return nullptr; }
+    m->n_head_local = cfg.n_head / N; m->n_head_kv_local = cfg.n_head_kv / N;
+    { const int nsb = cfg.n_ff / 256, base = nsb / N, rem = nsb % N; m->n_ff_local = (base + (R < rem ? 1 : 0)) * 256; if (cfg.n_ff % 256) m->n_ff_local = cfg.n_ff / N; }
+    const int E = cfg.n_embd, KV = m->n_head_kv_local * cfg.head_dim, Q = m->n_head_local * cfg.head_dim, F = m->n_ff_local, V = cfg.n_vocab;
+    // kind 0 random blocks, 1 ones(f32), 2 zeros(f32), 3 identity.  split: 0 whole, 1 rows [lo,hi) of a [gk x grows] tensor,
+    // 2 columns (k) [lo,hi) of every row -- a tensor-parallel shard is a slice of the SAME global tensor on every rank
+    struct Pending { ggml_tensor * t; int kind; uint64_t seed; float scale; int split; int64_t gk, grows, lo, hi; };
     std::vector<Pending> pend;
     uint64_t sd = opt.seed * 1000003ull + (cfg.eagle ? 7777 : 0);
     const float tiny = opt.predictable ? (getenv("EH_TINY") ? (float) atof(getenv("EH_TINY")) : 1e-4f) : 1.0f;     // residual branches contribute ~nothing in the predictable model
-    auto mat = [&](const char * which, int il, int64_t k, int64_t rows, float scale, const char * name) {
+    auto mat = [&](const char * which, int il, int64_t gk, int64_t grows, float scale, const char * name, int split = 0, int64_t lo = 0, int64_t hi = 0) {
+        const int64_t k = split == 2 ? hi - lo : gk, rows = split == 1 ? hi - lo : grows;
         ggml_tensor * t = w.new_tensor(weight_type_for(cfg, which, il), k, rows, 1, 1, name);
-        pend.push_back({t, 0, ++sd, scale}); m->weight_bytes += mh::nbytes(t); return t;
+        pend.push_back({t, 0, ++sd, scale, split, gk, grows, lo, hi}); m->weight_bytes += mh::nbytes(t); return t;
     };
+    const int Eg = cfg.n_embd, Qg = cfg.n_head * cfg.head_dim, KVg = cfg.n_head_kv * cfg.head_dim, Fg = cfg.n_ff;
+    int64_t f0 = 0; { const int nsb = cfg.n_ff / 256, base = nsb / N, rem = nsb % N; for (int r = 0; r < R; ++r) f0 += (int64_t)(base + (r < rem ? 1 : 0)) * 256; if (cfg.n_ff % 256) f0 = (int64_t) R * (cfg.n_ff / N); }
+    const int64_t q0 = (int64_t) R * Q, kv0 = (int64_t) R * KV;
+    const int sp_r = N > 1 ? 1 : 0, sp_k = N > 1 ? 2 : 0;
     char nm[64];
     m->layers.resize(cfg.n_layer);
     if (cfg.eagle) {
         m->fc = w.new_tensor(weight_type_for(cfg, "fc", 0), 2*E, E, 1, 1, "fc.weight"); m->weight_bytes += mh::nbytes(m->fc);
-        pend.push_back({m->fc, opt.predictable ? 3 : 0, ++sd, 0.02f});
-        m->fc_b = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, "fc.bias"); pend.push_back({m->fc_b, 2, 0, 0});
+        pend.push_back({m->fc, opt.predictable ? 3 : 0, ++sd, 0.02f, 0, 0, 0, 0, 0});
+        m->fc_b = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, "fc.bias"); pend.push_back({m->fc_b, 2, 0, 0, 0, 0, 0, 0, 0});
     }
     for (int il = 0; il < cfg.n_layer; ++il) {
         Layer & L = m->layers[il];
-        if (!cfg.eagle) { snprintf(nm, sizeof nm, "blk.%d.attn_norm.weight", il); L.attn_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, nm); pend.push_back({L.attn_norm, 1, 0, 0}); }
-        snprintf(nm, sizeof nm, "blk.%d.attn_q.weight", il);      L.wq = mat("wq", il, E, Q, 0.02f, nm);
-        snprintf(nm, sizeof nm, "blk.%d.attn_k.weight", il);      L.wk = mat("wk", il, E, KV, 0.02f, nm);
-        snprintf(nm, sizeof nm, "blk.%d.attn_v.weight", il);      L.wv = mat("wv", il, E, KV, 0.02f, nm);
-        snprintf(nm, sizeof nm, "blk.%d.attn_output.weight", il); L.wo = mat("wo", il, Q, E, 0.02f * tiny, nm);
-        snprintf(nm, sizeof nm, "blk.%d.ffn_norm.weight", il);    L.ffn_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, nm); pend.push_back({L.ffn_norm, 1, 0, 0});
-        snprintf(nm, sizeof nm, "blk.%d.ffn_gate.weight", il);    L.gate = mat("gate", il, E, F, 0.02f, nm);
-        snprintf(nm, sizeof nm, "blk.%d.ffn_up.weight", il);      L.up = mat("up", il, E, F, 0.02f, nm);
-        snprintf(nm, sizeof nm, "blk.%d.ffn_down.weight", il);    L.down = mat("down", il, F, E, 0.02f * tiny, nm);
+        if (!cfg.eagle) { snprintf(nm, sizeof nm, "blk.%d.attn_norm.weight", il); L.attn_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, nm); pend.push_back({L.attn_norm, 1, 0, 0, 0, 0, 0, 0, 0}); }
+        snprintf(nm, sizeof nm, "blk.%d.attn_q.weight", il);      L.wq = mat("wq", il, Eg, Qg, 0.02f, nm, sp_r, q0, q0 + Q);
+        snprintf(nm, sizeof nm, "blk.%d.attn_k.weight", il);      L.wk = mat("wk", il, Eg, KVg, 0.02f, nm, sp_r, kv0, kv0 + KV);
+        snprintf(nm, sizeof nm, "blk.%d.attn_v.weight", il);      L.wv = mat("wv", il, Eg, KVg, 0.02f, nm, sp_r, kv0, kv0 + KV);
+        snprintf(nm, sizeof nm, "blk.%d.attn_output.weight", il); L.wo = mat("wo", il, Qg, Eg, 0.02f * tiny, nm, sp_k, q0, q0 + Q);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_norm.weight", il);    L.ffn_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, nm); pend.push_back({L.ffn_norm, 1, 0, 0, 0, 0, 0, 0, 0});
+        snprintf(nm, sizeof nm, "blk.%d.ffn_gate.weight", il);    L.gate = mat("gate", il, Eg, Fg, 0.02f, nm, sp_r, f0, f0 + F);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_up.weight", il);      L.up = mat("up", il, Eg, Fg, 0.02f, nm, sp_r, f0, f0 + F);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_down.weight", il);    L.down = mat("down", il, Fg, Eg, 0.02f * tiny, nm, sp_k, f0, f0 + F);
     }
     if (!cfg.eagle) {
-        m->output_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, "output_norm.weight"); pend.push_back({m->output_norm, 1, 0, 0});
+        m->output_norm = w.new_tensor(GGML_TYPE_F32, E, 1, 1, 1, "output_norm.weight"); pend.push_back({m->output_norm, 1, 0, 0, 0, 0, 0, 0, 0});
         m->output = mat("output", 0, E, V, 0.02f, "output.weight");
     } else {
         m->lm_head_from = target;
@@ -228,12 +241,23 @@ Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const
     for (auto b : w.buffers) b->iface.clear(b, 0);
 
     // fill + upload, one tensor at a time through set_tensor (what llama_model_loader::load_all_data does)
-    std::vector<uint8_t> stage;
+    std::vector<uint8_t> stage, gstage;
     std::vector<uint8_t> out_rows;                          // kept for the predictable embedding construction
     for (auto & p : pend) {
         const size_t n = mh::nbytes(p.t);
         stage.resize(n);
-        if (p.kind == 0) fill_blocks(p.t->type, stage.data(), p.t->ne[1], p.t->ne[0], p.seed, p.scale);
+        if (p.kind == 0 && p.split == 0) fill_blocks(p.t->type, stage.data(), p.t->ne[1], p.t->ne[0], p.seed, p.scale);
+        else if (p.kind == 0) {                               // generate the global tensor, keep this rank's slice
+            const auto tr = mh::traits(p.t->type);
+            const size_t grb = mh::row_size(p.t->type, p.gk);
+            gstage.resize((size_t) p.grows * grb);
+            fill_blocks(p.t->type, gstage.data(), p.grows, p.gk, p.seed, p.scale);
+            if (p.split == 1) memcpy(stage.data(), gstage.data() + (size_t) p.lo * grb, n);
+            else {
+                const size_t lrb = mh::row_size(p.t->type, p.hi - p.lo), off = (size_t)(p.lo / tr.blck) * tr.size;
+                for (int64_t r = 0; r < p.grows; ++r) memcpy(stage.data() + (size_t) r * lrb, gstage.data() + (size_t) r * grb + off, lrb);
+            }
+        }
         else if (p.kind == 1) { float * f = (float *) stage.data(); for (size_t i = 0; i < n/4; ++i) f[i] = 1.0f; }
         else if (p.kind == 2) memset(stage.data(), 0, n);
         else fill_identity(p.t->type, stage.data(), p.t->ne[1], p.t->ne[0]);
@@ -287,7 +311,12 @@ int Model::decode(const Batch & b, bool want_hidden) {
     const uint32_t pad = 32;                                 // llama_kv_cache_get_padding without flash-attn
     kv.n = std::min(kv.size, std::max(pad, (kv.cell_max() + pad - 1) / pad * pad));
     const int n_kv = (int) kv.n, kv_head = (int) kv.head;
-    const int E = cfg.n_embd, H = cfg.n_head, Hkv = cfg.n_head_kv, D = cfg.head_dim, n_ctx = cfg.n_ctx;
+    static const bool force_tp = getenv("EH_FORCE_TP") != nullptr;     // run the segmented path + collectives even with one rank (single-GPU rehearsal)
+    const bool tp = cfg.tp_size > 1 || (force_tp && allreduce && !cfg.eagle);
+    if (tp && !allreduce) return -5;
+    const int E = cfg.n_embd, H = n_head_local, Hkv = n_head_kv_local, D = cfg.head_dim, n_ctx = cfg.n_ctx;
+    struct Cut { int node_end; ggml_tensor * t; };
+    std::vector<Cut> cuts;                                   // tensor parallel: partial sums to all-reduce, and where the graph is cut
     const int KVd = Hkv * D;
     n_outputs = 0; out_ids.clear();
     for (int i = 0; i < T; ++i) if (b.logits[i]) { out_ids.push_back(i); n_outputs++; }
@@ -341,7 +370,8 @@ int Model::decode(const Batch & b, bool want_hidden) {
         ggml_tensor * v = g.view_3d(v_l[il], n_kv, D, Hkv, (size_t) n_ctx * 2, (size_t) n_ctx * D * 2, 0);
         ggml_tensor * kqv = g.mul_mat(v, kq);
         cur = g.cont_2d(g.permute(kqv, 0, 2, 1, 3), (int64_t) D * H, n_tok);
-        cur = g.mul_mat(L.wo, cur);
+        cur = g.mul_mat(L.wo, cur);                            // TP: partial sum over this rank's heads
+        if (tp) cuts.push_back({ (int) g.nodes.size(), cur });
         if (il == cfg.n_layer - 1) {                           // skip unused tokens :1737-1743
             n_tok = n_outputs;
             cur = g.get_rows(cur, inp_out);
@@ -354,20 +384,25 @@ int Model::decode(const Batch & b, bool want_hidden) {
         gate = g.unary(gate, GGML_UNARY_OP_SILU);
         ggml_tensor * up = g.mul_mat(L.up, cur);
         cur = g.mul(gate, up);
-        cur = g.mul_mat(L.down, cur);
+        cur = g.mul_mat(L.down, cur);                          // TP: partial sum over this rank's slice of n_ff
+        if (tp) cuts.push_back({ (int) g.nodes.size(), cur });
         cur = g.add(cur, ffn_inp);
         snprintf(nm, sizeof nm, "l_out-%d", il); g.set_name(cur, nm);
         inpL = cur;
     }
-    cur = g.rms_norm(inpL, cfg.rms_eps);
-    if (output_norm) cur = g.mul(cur, output_norm);
-    g.set_name(cur, "result_norm");
-    ggml_tensor * result_norm = cur;
-    ggml_tensor * head = cfg.eagle ? lm_head_from->output : output;
-    cur = g.mul_mat(head, cur);
-    g.set_name(cur, "result_output");
-    ggml_tensor * result_output = cur;
-    result_norm->flags |= GGML_TENSOR_FLAG_OUTPUT; result_output->flags |= GGML_TENSOR_FLAG_OUTPUT;
+    ggml_tensor * result_norm = nullptr, * result_output = nullptr;
+    const bool head_here = !tp || cfg.tp_rank == 0;          // TP: the LM head (and the hidden-state channel) live on rank 0
+    if (head_here) {
+        cur = g.rms_norm(inpL, cfg.rms_eps);
+        if (output_norm) cur = g.mul(cur, output_norm);
+        g.set_name(cur, "result_norm");
+        result_norm = cur;
+        ggml_tensor * head = cfg.eagle ? lm_head_from->output : output;
+        cur = g.mul_mat(head, cur);
+        g.set_name(cur, "result_output");
+        result_output = cur;
+        result_norm->flags |= GGML_TENSOR_FLAG_OUTPUT; result_output->flags |= GGML_TENSOR_FLAG_OUTPUT;
+    }
     last_n_nodes = (int) g.nodes.size();
     if (!g.alloc()) return -3;
     const double t1 = now_us();
@@ -389,14 +424,27 @@ int Model::decode(const Batch & b, bool want_hidden) {
     g.set(kq_mask, mask.data(), 0, mask.size() * 4);
     const double t2 = now_us();
 
-    const enum ggml_status st = g.compute();
+    enum ggml_status st = GGML_STATUS_SUCCESS;
+    if (!tp) st = g.compute();
+    else {
+        int n0 = 0;
+        for (auto & c : cuts) {
+            st = g.compute_range(n0, c.node_end); if (st != GGML_STATUS_SUCCESS) break;
+            allreduce(allreduce_user, c.t->data, mh::nelements(c.t)); n_allreduce++;
+            n0 = c.node_end;
+        }
+        if (st == GGML_STATUS_SUCCESS) st = g.compute_range(n0, (int) g.nodes.size());
+        be->synchronize();
+    }
     const double t3 = now_us();
     if (st != GGML_STATUS_SUCCESS) { return st == GGML_STATUS_ABORTED ? 2 : -4; }
 
     // ---- outputs
-    logits.resize((size_t) n_outputs * cfg.n_vocab);
-    g.get(result_output, logits.data(), 0, logits.size() * 4);
-    if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get(result_norm, hidden.data(), 0, hidden.size() * 4); }
+    if (head_here) {
+        logits.resize((size_t) n_outputs * cfg.n_vocab);
+        g.get(result_output, logits.data(), 0, logits.size() * 4);
+        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get(result_norm, hidden.data(), 0, hidden.size() * 4); }
+    } else { logits.clear(); hidden.clear(); }
     kv.head += T;
     if (kv.head >= kv.size) kv.head = 0;
     const double t4 = now_us();

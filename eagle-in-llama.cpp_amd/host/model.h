@@ -24,6 +24,7 @@ struct ModelConfig {
     int ftype = FTYPE_Q4_K_M;
     bool eagle = false;               // EAGLE head: fc [2*n_embd -> n_embd] + bias + ReLU, no attn_norm / output_norm weights
     int n_seq_max = 16;
+    int tp_rank = 0, tp_size = 1;     // tensor parallel: this process holds shard tp_rank of tp_size (one process per GPU)
 };
 
 struct Batch {                          // llama_batch: token, pos, seq ids, logits flag (R/include/llama.h:236-253)
@@ -72,6 +73,12 @@ struct Model {
     std::vector<ggml_tensor *> k_l, v_l;
     KVCache kv;
     const Model * lm_head_from = nullptr;   // EAGLE: LM head borrowed from the target (build_lmhead on llm2)
+    // tensor parallel: sum a [n_floats] fp32 buffer (device memory of this model's backend) over all ranks, in place,
+    // ordered after everything already submitted to the backend (RCCL on the backend stream; gloo in the CPU tests)
+    typedef void (*allreduce_fn)(void * user, void * data, int64_t n_floats);
+    allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
+    int n_head_local = 0, n_head_kv_local = 0, n_ff_local = 0;
+    int64_t n_allreduce = 0;
     size_t weight_bytes = 0;          // bytes of all mat-mul weights resident on the device (for the roofline)
 
     // outputs of the last decode

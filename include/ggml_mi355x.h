@@ -22,6 +22,8 @@
  * Named extension points the reference looks up with reg->iface.get_proc_address():
  *   "ggml_backend_split_buffer_type"  (R/src/llama-model.cpp:310-322, -sm row)  -> ggml_backend_mi355x_split_buffer_type
  *   "ggml_backend_get_features"       (R/src/llama.cpp:12044)                    -> feature list
+ * and one extension of ours, "ggml_backend_mi355x_stream": void * (*)(ggml_backend_t) -> the hipStream_t of a backend
+ * instance, for hosts that enqueue RCCL collectives between graph segments (tensor parallel, host/tp.cpp).
  */
 #ifndef GGML_MI355X_H
 #define GGML_MI355X_H
