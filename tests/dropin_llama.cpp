@@ -1,0 +1,179 @@
+// tests/dropin_llama.cpp -- drop-in proof under the REAL reference stack (test infrastructure only).
+//
+// Compiled in the build container against the reference's own headers (R/include/llama.h, R/ggml/include/*.h) and
+// linked with oracle/_ref/libllama-ref.so + libggml-ref.so (the reference's src/*.cpp and ggml, built unmodified by
+// oracle/Makefile); the binary lands in oracle/_ref/ and runs on the GPU box.
+//
+// It writes a small synthetic GGUF pair (llama target + eagle draft head, random weights quantised by the reference's
+// own ggml_quantize_chunk), loads our plugin through the reference's loader (ggml_backend_load), and runs the
+// reference's llama_decode() / llama_decode_initial() / llama_decode_draft() twice: all layers on the MI355X device
+// (-ngl 99 equivalent) and all on the reference CPU backend.  The reference's scheduler, graph allocator (memory
+// re-use!), KV cache, mask builder and hidden-state channel are all live; only graph_compute is ours.
+// Output: one line per check with the relative error; exit code 0 iff every check passes.
+#include "llama.h"
+#include "ggml.h"
+#include "ggml-backend.h"
+#include "gguf.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+struct dims { int n_embd, n_head, n_head_kv, n_ff, n_layer, n_vocab, n_ctx; };
+
+static void add_tensor(gguf_context * g, ggml_context * ctx, std::mt19937 & rng, const char * name, ggml_type type, int64_t ne0, int64_t ne1, float scale, bool ones = false) {
+    ggml_tensor * t = ne1 > 0 ? ggml_new_tensor_2d(ctx, type, ne0, ne1) : ggml_new_tensor_1d(ctx, type, ne0);
+    ggml_set_name(t, name);
+    const int64_t n = ggml_nelements(t);
+    std::vector<float> f(n);
+    std::normal_distribution<float> nd(0.0f, scale);
+    for (auto & v : f) v = ones ? 1.0f : nd(rng);
+    if (type == GGML_TYPE_F32) memcpy(t->data, f.data(), n * 4);
+    else ggml_quantize_chunk(type, f.data(), t->data, 0, ne1 > 0 ? ne1 : 1, ne0, nullptr);
+    gguf_add_tensor(g, t);
+}
+
+static void write_model(const char * path, const dims & d, bool eagle, ggml_type wtype, unsigned seed) {
+    gguf_context * g = gguf_init_empty();
+    const char * arch = eagle ? "eagle" : "llama";
+    auto key = [&](const char * suffix) { return std::string(arch) + "." + suffix; };
+    gguf_set_val_str(g, "general.architecture", arch);
+    gguf_set_val_str(g, "general.name", eagle ? "synthetic-eagle" : "synthetic-llama");
+    gguf_set_val_u32(g, key("context_length").c_str(), d.n_ctx);
+    gguf_set_val_u32(g, key("embedding_length").c_str(), d.n_embd);
+    gguf_set_val_u32(g, key("block_count").c_str(), eagle ? 1 : d.n_layer);
+    gguf_set_val_u32(g, key("feed_forward_length").c_str(), d.n_ff);
+    gguf_set_val_u32(g, key("attention.head_count").c_str(), d.n_head);
+    gguf_set_val_u32(g, key("attention.head_count_kv").c_str(), d.n_head_kv);
+    gguf_set_val_u32(g, key("rope.dimension_count").c_str(), d.n_embd / d.n_head);
+    gguf_set_val_f32(g, key("attention.layer_norm_rms_epsilon").c_str(), 1e-6f);
+    gguf_set_val_u32(g, key("vocab_size").c_str(), d.n_vocab);
+    gguf_set_val_str(g, "tokenizer.ggml.model", "no_vocab");
+    const size_t mem = (size_t) 64 << 20;
+    ggml_init_params ip = { mem * 8, nullptr, false };
+    ggml_context * ctx = ggml_init(ip);
+    std::mt19937 rng(seed);
+    const int hd = d.n_embd / d.n_head, kv = hd * d.n_head_kv;
+    char nm[128];
+    add_tensor(g, ctx, rng, "token_embd.weight", GGML_TYPE_F32, d.n_embd, d.n_vocab, 1.0f);
+    if (!eagle) {
+        add_tensor(g, ctx, rng, "output_norm.weight", GGML_TYPE_F32, d.n_embd, 0, 0, true);
+        add_tensor(g, ctx, rng, "output.weight", GGML_TYPE_Q6_K, d.n_embd, d.n_vocab, 0.05f);
+    } else {
+        add_tensor(g, ctx, rng, "fc.weight", wtype, 2 * d.n_embd, d.n_embd, 0.03f);
+        add_tensor(g, ctx, rng, "fc.bias", GGML_TYPE_F32, d.n_embd, 0, 0.1f);
+    }
+    for (int i = 0; i < (eagle ? 1 : d.n_layer); ++i) {
+        if (!eagle) { snprintf(nm, sizeof nm, "blk.%d.attn_norm.weight", i); add_tensor(g, ctx, rng, nm, GGML_TYPE_F32, d.n_embd, 0, 0, true); }
+        snprintf(nm, sizeof nm, "blk.%d.attn_q.weight", i);      add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_embd, 0.05f);
+        snprintf(nm, sizeof nm, "blk.%d.attn_k.weight", i);      add_tensor(g, ctx, rng, nm, wtype, d.n_embd, kv, 0.05f);
+        snprintf(nm, sizeof nm, "blk.%d.attn_v.weight", i);      add_tensor(g, ctx, rng, nm, (i % 2) ? GGML_TYPE_Q6_K : wtype, d.n_embd, kv, 0.05f);
+        snprintf(nm, sizeof nm, "blk.%d.attn_output.weight", i); add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_embd, 0.05f);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_norm.weight", i);    add_tensor(g, ctx, rng, nm, GGML_TYPE_F32, d.n_embd, 0, 0, true);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_gate.weight", i);    add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_ff, 0.05f);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_up.weight", i);      add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_ff, 0.05f);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_down.weight", i);    add_tensor(g, ctx, rng, nm, (i % 2) ? GGML_TYPE_Q6_K : wtype, d.n_ff, d.n_embd, 0.05f);
+    }
+    gguf_write_to_file(g, path, false);
+    gguf_free(g); ggml_free(ctx);
+}
+
+struct run_out { std::vector<float> prompt_logits, step_logits, tree_logits, draft_logits; };
+
+static std::vector<float> grab(llama_context * c, int i, int n_vocab) { const float * p = llama_get_logits_ith(c, i); return std::vector<float>(p, p + n_vocab); }
+
+static bool run(const std::string & tgt_path, const std::string & dft_path, const dims & d, int ngl, run_out & o) {
+    llama_model_params mp = llama_model_default_params();
+    mp.n_gpu_layers = ngl; mp.use_mmap = true;
+    llama_model * mt = llama_model_load_from_file(tgt_path.c_str(), mp);
+    llama_model * md = llama_model_load_from_file(dft_path.c_str(), mp);
+    if (!mt || !md) { fprintf(stderr, "model load failed\n"); return false; }
+    llama_context_params cp = llama_context_default_params();
+    cp.n_ctx = d.n_ctx; cp.n_batch = 64; cp.n_ubatch = 64; cp.n_seq_max = 4; cp.embeddings = true;    // the fork only yields logits with embeddings on
+    cp.n_threads = 4; cp.n_threads_batch = 4;
+    llama_context * ct = llama_init_from_model(mt, cp);
+    llama_context * cd = llama_init_from_model(md, cp);
+    if (!ct || !cd) { fprintf(stderr, "context init failed\n"); return false; }
+    const int V = d.n_vocab;
+    // 1. prompt: 12 tokens, logits for all
+    llama_batch b = llama_batch_init(64, 0, 4);
+    auto add = [&](int tok, int pos, std::vector<int> seqs, bool lg) { const int i = b.n_tokens; b.token[i] = tok; b.pos[i] = pos; b.n_seq_id[i] = (int) seqs.size(); for (size_t s = 0; s < seqs.size(); ++s) b.seq_id[i][s] = seqs[s]; b.logits[i] = lg; b.n_tokens++; };
+    b.n_tokens = 0;
+    for (int i = 0; i < 12; ++i) add(5 + i * 7 % V, i, {0}, true);
+    if (llama_decode(ct, b) != 0) { fprintf(stderr, "llama_decode(prompt) failed\n"); return false; }
+    for (int i = 0; i < 12; ++i) { auto v = grab(ct, i, V); o.prompt_logits.insert(o.prompt_logits.end(), v.begin(), v.end()); }
+    // 2. single-token step
+    b.n_tokens = 0; add(33, 12, {0}, true);
+    if (llama_decode(ct, b) != 0) return false;
+    o.step_logits = grab(ct, 0, V);
+    // 3. tree verify: two branches sharing the prefix (llama_kv_cache_seq_cp, as the tree driver does)
+    llama_kv_cache_seq_cp(ct, 0, 1, -1, -1); llama_kv_cache_seq_cp(ct, 0, 2, -1, -1);
+    b.n_tokens = 0; add(40, 13, {1}, true); add(41, 14, {1}, true); add(50, 13, {2}, true); add(51, 14, {2}, true); add(52, 15, {2}, true);
+    if (llama_decode(ct, b) != 0) return false;
+    for (int i = 0; i < 5; ++i) { auto v = grab(ct, i, V); o.tree_logits.insert(o.tree_logits.end(), v.begin(), v.end()); }
+    // 4. EAGLE channel: target step that hands result_norm to the draft, then two draft steps on the draft's own feature.
+    //    The draft context first ingests a 12-token batch with plain llama_decode (as the tree driver does for the prompt):
+    //    besides priming its KV cache this sizes its output buffer, without which the reference's hidden-state pointer
+    //    lands past the end of the allocation and corrupts the heap on ANY backend.
+    b.n_tokens = 0;
+    for (int i = 0; i < 12; ++i) add(5 + i * 7 % V, i, {0}, true);
+    if (llama_decode(cd, b) != 0) { fprintf(stderr, "llama_decode(draft prompt) failed\n"); return false; }
+    b.n_tokens = 0; add(9, 12, {0}, true);                      // a 1-output call re-seats the hidden pointer INSIDE the (larger) buffer
+    if (llama_decode(cd, b) != 0) return false;
+    llama_kv_cache_seq_rm(cd, 0, 12, -1);
+    llama_kv_cache_seq_keep(ct, 0);
+    b.n_tokens = 0; add(60, 13, {0}, true);
+    if (llama_decode_initial(ct, b, cd) != 0) { fprintf(stderr, "llama_decode_initial failed\n"); return false; }
+    b.n_tokens = 0; add(61, 12, {0}, true);
+    if (llama_decode_draft(cd, b, ct) != 0) { fprintf(stderr, "llama_decode_draft failed\n"); return false; }
+    { auto v = grab(cd, 0, V); o.draft_logits.insert(o.draft_logits.end(), v.begin(), v.end()); }
+    b.n_tokens = 0; add(62, 13, {0}, true);
+    if (llama_decode_draft(cd, b, ct) != 0) return false;
+    { auto v = grab(cd, 0, V); o.draft_logits.insert(o.draft_logits.end(), v.begin(), v.end()); }
+    llama_batch_free(b);
+    llama_free(ct); llama_free(cd); llama_model_free(mt); llama_model_free(md);
+    return true;
+}
+
+static bool check(const char * what, const std::vector<float> & a, const std::vector<float> & b, int V, double tol) {
+    if (a.size() != b.size() || a.empty()) { printf("%-14s size mismatch %zu vs %zu\n", what, a.size(), b.size()); return false; }
+    double num = 0, den = 0, mx = 0, mb = 0; int same = 0, rows = (int)(a.size() / V);
+    for (size_t i = 0; i < a.size(); ++i) { const double e = (double) a[i] - b[i]; num += e*e; den += (double) b[i]*b[i]; if (fabs(e) > mx) mx = fabs(e); if (fabs(b[i]) > mb) mb = fabs(b[i]); }
+    for (int r = 0; r < rows; ++r) { int ia = 0, ib = 0; for (int i = 1; i < V; ++i) { if (a[r*V+i] > a[r*V+ia]) ia = i; if (b[r*V+i] > b[r*V+ib]) ib = i; } same += ia == ib; }
+    const double l2 = sqrt(num / (den + 1e-30));
+    const bool ok = l2 < tol && std::isfinite(l2);
+    printf("%-14s rows %2d  rel-L2 %.3e  max-rel %.3e  argmax equal %d/%d  %s\n", what, rows, l2, mx / (mb + 1e-30), same, rows, ok ? "OK" : "FAIL");
+    return ok;
+}
+
+int main(int argc, char ** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s /path/libggml-mi355x.so [workdir]\n", argv[0]); return 2; }
+    const std::string work = argc > 2 ? argv[2] : "/tmp";
+    llama_backend_init();
+    const bool cpu_only = strcmp(argv[1], "cpu") == 0;          // self-check of this program without a GPU: CPU vs CPU
+    if (!cpu_only) {
+        ggml_backend_reg_t reg = ggml_backend_load(argv[1]);
+        if (!reg) { fprintf(stderr, "ggml_backend_load(%s) failed\n", argv[1]); return 2; }
+        printf("loaded backend '%s' with %zu device(s)\n", ggml_backend_reg_name(reg), ggml_backend_reg_dev_count(reg));
+        if (ggml_backend_reg_dev_count(reg) == 0) { fprintf(stderr, "no MI355X device\n"); return 3; }
+    }
+    const dims d = { 1024, 8, 4, 2816, 4, 4096, 256 };            // GQA, n_ff not a multiple of 1024, mixed Q4_K / Q6_K like Q4_K_M
+    const std::string tp = work + "/dropin_tgt.gguf", dp = work + "/dropin_dft.gguf";
+    write_model(tp.c_str(), d, false, GGML_TYPE_Q4_K, 1);
+    write_model(dp.c_str(), d, true, GGML_TYPE_Q4_K, 2);
+    run_out gpu, cpu;
+    if (!run(tp, dp, d, 99, gpu)) return 4;
+    if (!run(tp, dp, d, 0, cpu)) return 5;
+    bool ok = true;
+    // tolerance: DESIGN.md 4 (int8 rounding flips of the quantised activations; calibrated against the reference's own two builds)
+    ok &= check("prompt", gpu.prompt_logits, cpu.prompt_logits, d.n_vocab, 1e-2);
+    ok &= check("step", gpu.step_logits, cpu.step_logits, d.n_vocab, 1e-2);
+    ok &= check("tree-verify", gpu.tree_logits, cpu.tree_logits, d.n_vocab, 1e-2);
+    ok &= check("eagle-draft", gpu.draft_logits, cpu.draft_logits, d.n_vocab, 1e-2);
+    printf(ok ? "DROP-IN OK\n" : "DROP-IN FAILED\n");
+    remove(tp.c_str()); remove(dp.c_str());
+    return ok ? 0 : 1;
+}
