@@ -196,7 +196,7 @@ Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const
     struct Pending { ggml_tensor * t; int kind; uint64_t seed; float scale; int split; int64_t gk, grows, lo, hi; };
     std::vector<Pending> pend;
     uint64_t sd = opt.seed * 1000003ull + (cfg.eagle ? 7777 : 0);
-    const float tiny = opt.predictable ? (getenv("EH_TINY") ? (float) atof(getenv("EH_TINY")) : 1e-4f) : 1.0f;     // residual branches contribute ~nothing in the predictable model
+    const float tiny = opt.predictable ? (getenv("EH_TINY") ? (float) atof(getenv("EH_TINY")) : 1e-4f) : 0.1f;     // residual branches: ~nothing in the predictable model, a few % of the stream otherwise (as in a trained net; O(1) branches make the quantised model chaotic)
     auto mat = [&](const char * which, int il, int64_t gk, int64_t grows, float scale, const char * name, int split = 0, int64_t lo = 0, int64_t hi = 0) {
         const int64_t k = split == 2 ? hi - lo : gk, rows = split == 1 ? hi - lo : grows;
         ggml_tensor * t = w.new_tensor(weight_type_for(cfg, which, il), k, rows, 1, 1, name);

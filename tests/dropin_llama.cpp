@@ -10,6 +10,12 @@
 // (-ngl 99 equivalent) and all on the reference CPU backend.  The reference's scheduler, graph allocator (memory
 // re-use!), KV cache, mask builder and hidden-state channel are all live; only graph_compute is ours.
 // Output: one line per check with the relative error; exit code 0 iff every check passes.
+//
+// Weights: the residual branches (attn_output, ffn_down) are scaled so that a layer perturbs the residual stream by a
+// few percent, as in a trained network.  With O(1) random branches the model is chaotic: int8 activation rounding
+// turns a 1e-7 difference in fp32 summation order into ~sqrt(eps) output noise per quantised mat-mul (measured with
+// DROPIN_TRACE=1: 2e-7 -> 5e-4 -> 2e-3 -> 7e-3 over one layer, for the reference's own AVX2-vs-scalar builds alike),
+// which says nothing about the backend under test.
 #include "llama.h"
 #include "ggml.h"
 #include "ggml-backend.h"
@@ -71,17 +77,30 @@ static void write_model(const char * path, const dims & d, bool eagle, ggml_type
         snprintf(nm, sizeof nm, "blk.%d.attn_q.weight", i);      add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_embd, 0.05f);
         snprintf(nm, sizeof nm, "blk.%d.attn_k.weight", i);      add_tensor(g, ctx, rng, nm, wtype, d.n_embd, kv, 0.05f);
         snprintf(nm, sizeof nm, "blk.%d.attn_v.weight", i);      add_tensor(g, ctx, rng, nm, (i % 2) ? GGML_TYPE_Q6_K : wtype, d.n_embd, kv, 0.05f);
-        snprintf(nm, sizeof nm, "blk.%d.attn_output.weight", i); add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_embd, 0.05f);
+        snprintf(nm, sizeof nm, "blk.%d.attn_output.weight", i); add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_embd, 0.004f);
         snprintf(nm, sizeof nm, "blk.%d.ffn_norm.weight", i);    add_tensor(g, ctx, rng, nm, GGML_TYPE_F32, d.n_embd, 0, 0, true);
         snprintf(nm, sizeof nm, "blk.%d.ffn_gate.weight", i);    add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_ff, 0.05f);
         snprintf(nm, sizeof nm, "blk.%d.ffn_up.weight", i);      add_tensor(g, ctx, rng, nm, wtype, d.n_embd, d.n_ff, 0.05f);
-        snprintf(nm, sizeof nm, "blk.%d.ffn_down.weight", i);    add_tensor(g, ctx, rng, nm, (i % 2) ? GGML_TYPE_Q6_K : wtype, d.n_ff, d.n_embd, 0.05f);
+        snprintf(nm, sizeof nm, "blk.%d.ffn_down.weight", i);    add_tensor(g, ctx, rng, nm, (i % 2) ? GGML_TYPE_Q6_K : wtype, d.n_ff, d.n_embd, 0.004f);
     }
     gguf_write_to_file(g, path, false);
     gguf_free(g); ggml_free(ctx);
 }
 
-struct run_out { std::vector<float> prompt_logits, step_logits, tree_logits, draft_logits; };
+struct run_out { std::vector<float> prompt_logits, step_logits, tree_logits, draft_logits; std::vector<std::pair<std::string, std::vector<float>>> trace; };
+
+// DROPIN_TRACE=1: record every f32 node of the first target decode through the scheduler's eval callback
+static bool g_trace = false;
+static run_out * g_cur = nullptr;
+static bool trace_cb(struct ggml_tensor * t, bool ask, void * user) {
+    (void) user;
+    if (!g_trace || !g_cur) return false;
+    if (ask) return t->type == GGML_TYPE_F32 && g_cur->trace.size() < 400;
+    std::vector<float> v(ggml_nelements(t));
+    if (ggml_is_contiguous(t)) ggml_backend_tensor_get(t, v.data(), 0, ggml_nbytes(t));
+    g_cur->trace.emplace_back(std::string(t->name) + " [" + ggml_op_name(t->op) + "]", std::move(v));
+    return true;
+}
 
 static std::vector<float> grab(llama_context * c, int i, int n_vocab) { const float * p = llama_get_logits_ith(c, i); return std::vector<float>(p, p + n_vocab); }
 
@@ -94,6 +113,8 @@ static bool run(const std::string & tgt_path, const std::string & dft_path, cons
     llama_context_params cp = llama_context_default_params();
     cp.n_ctx = d.n_ctx; cp.n_batch = 64; cp.n_ubatch = 64; cp.n_seq_max = 4; cp.embeddings = true;    // the fork only yields logits with embeddings on
     cp.n_threads = 4; cp.n_threads_batch = 4;
+    g_trace = getenv("DROPIN_TRACE") != nullptr; g_cur = &o;
+    if (g_trace) { cp.cb_eval = trace_cb; cp.cb_eval_user_data = nullptr; }
     llama_context * ct = llama_init_from_model(mt, cp);
     llama_context * cd = llama_init_from_model(md, cp);
     if (!ct || !cd) { fprintf(stderr, "context init failed\n"); return false; }
@@ -105,6 +126,7 @@ static bool run(const std::string & tgt_path, const std::string & dft_path, cons
     for (int i = 0; i < 12; ++i) add(5 + i * 7 % V, i, {0}, true);
     if (llama_decode(ct, b) != 0) { fprintf(stderr, "llama_decode(prompt) failed\n"); return false; }
     for (int i = 0; i < 12; ++i) { auto v = grab(ct, i, V); o.prompt_logits.insert(o.prompt_logits.end(), v.begin(), v.end()); }
+    g_cur = nullptr;                                            // trace only the first decode
     // 2. single-token step
     b.n_tokens = 0; add(33, 12, {0}, true);
     if (llama_decode(ct, b) != 0) return false;
@@ -167,12 +189,20 @@ int main(int argc, char ** argv) {
     run_out gpu, cpu;
     if (!run(tp, dp, d, 99, gpu)) return 4;
     if (!run(tp, dp, d, 0, cpu)) return 5;
+    if (getenv("DROPIN_TRACE")) {
+        const size_t n = std::min(gpu.trace.size(), cpu.trace.size());
+        for (size_t i = 0; i < n; ++i) {
+            const auto & a = gpu.trace[i].second; const auto & b = cpu.trace[i].second;
+            double num = 0, den = 0; for (size_t j = 0; j < std::min(a.size(), b.size()); ++j) { const double e = (double) a[j] - b[j]; num += e*e; den += (double) b[j]*b[j]; }
+            printf("trace %3zu %-40s | %-40s n=%zu/%zu relL2 %.3e\n", i, gpu.trace[i].first.c_str(), cpu.trace[i].first.c_str(), a.size(), b.size(), sqrt(num/(den+1e-30)));
+        }
+    }
     bool ok = true;
-    // tolerance: DESIGN.md 4 (int8 rounding flips of the quantised activations; calibrated against the reference's own two builds)
-    ok &= check("prompt", gpu.prompt_logits, cpu.prompt_logits, d.n_vocab, 1e-2);
-    ok &= check("step", gpu.step_logits, cpu.step_logits, d.n_vocab, 1e-2);
-    ok &= check("tree-verify", gpu.tree_logits, cpu.tree_logits, d.n_vocab, 1e-2);
-    ok &= check("eagle-draft", gpu.draft_logits, cpu.draft_logits, d.n_vocab, 1e-2);
+    // tolerance: the north-star bound, 1e-3 relative
+    ok &= check("prompt", gpu.prompt_logits, cpu.prompt_logits, d.n_vocab, 1e-3);
+    ok &= check("step", gpu.step_logits, cpu.step_logits, d.n_vocab, 1e-3);
+    ok &= check("tree-verify", gpu.tree_logits, cpu.tree_logits, d.n_vocab, 1e-3);
+    ok &= check("eagle-draft", gpu.draft_logits, cpu.draft_logits, d.n_vocab, 1e-3);
     printf(ok ? "DROP-IN OK\n" : "DROP-IN FAILED\n");
     remove(tp.c_str()); remove(dp.c_str());
     return ok ? 0 : 1;

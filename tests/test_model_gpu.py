@@ -41,17 +41,18 @@ def test_logits_match_reference_cpu(ea, gpu, ref_cpu, ftype, config):
     # (GPU vs CPU, or the reference's own AVX2 vs scalar builds -- see test_reference_builds_disagree_alike) is the
     # fp32 summation order, ~1e-7.  That is enough to flip, rarely, one int8 activation rounding (x*iscale = n+0.5)
     # or one f16 rounding of q / p; a flipped int8 at k = 256 moves one output by ~1e-3 of the row scale.  Hence:
-    # On this deliberately tiny, random (chaotic) model the reference's two builds differ from EACH OTHER by
-    # 1.5e-3 .. 6e-3 relative L2 (measured; asserted below), so the bound here is 2e-2 L2 / 5e-2 max; at real model
-    # widths (k >= 4096) a flip is ~16x smaller and test_ops_gpu.py holds 2e-5 per mat-vec.  Argmax must agree
-    # wherever the top-2 margin exceeds the bound.
+    # With O(1) random residual branches such a model is chaotic (each quantised mat-mul turns eps into ~sqrt(eps)):
+    # the reference's own AVX2 and scalar builds then differ by 1.5e-3 .. 6e-3.  The synthetic weights therefore scale
+    # the residual branches to a few % of the stream, as in a trained net (host/model.cpp), and the bound is the
+    # north-star one: relative L2 <= 1e-3 on every tensor, the same bound the reference's two builds must meet
+    # (test_reference_builds_disagree_alike); argmax equal wherever the margin is clear.
     for i, (a, b) in enumerate(zip(*outs)):
         assert a.shape == b.shape
         l2 = float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))
-        assert l2 < 2e-2, (i, l2)
-        assert rel(a, b) < 5e-2, (i, rel(a, b))
+        assert l2 < 1e-3, (i, l2)
+        assert rel(a, b) < 5e-3, (i, rel(a, b))
         if a.shape[-1] in (512, 768):                                               # logits rows
-            srt = np.sort(b, -1); clear = (srt[:, -1] - srt[:, -2]) > 1e-1 * np.abs(b).max()
+            srt = np.sort(b, -1); clear = (srt[:, -1] - srt[:, -2]) > 1e-2 * np.abs(b).max()
             assert np.array_equal(a.argmax(-1)[clear], b.argmax(-1)[clear]), i
 
 
@@ -65,7 +66,7 @@ def test_reference_builds_disagree_alike(ea):
         outs.append(lg); m.close()
     l2 = float(np.linalg.norm(outs[0].astype(np.float64) - outs[1]) / np.linalg.norm(outs[1].astype(np.float64)))
     print("reference avx2 vs scalar: rel L2", l2, "max", rel(outs[0], outs[1]))
-    assert l2 < 1e-2
+    assert l2 < 1e-3
 
 
 @pytest.mark.parametrize("ftype", ["q4_k_m", "q8_0"])

@@ -28,7 +28,7 @@ def test_tp_matches_unsharded(ea, tmp_path, world):
     assert int(z["weight_bytes"]) < m.weight_bytes                 # the shard streams less than the whole model
     for a, b in ((z["lg"], lg), (z["hid"], hid), (z["lg1"], lg1), (z["hid1"], hid1)):
         l2 = float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))
-        assert l2 < 2e-2, l2                                       # same calibration as tests/test_model_gpu.py (int8 rounding flips)
+        assert l2 < 1e-3, l2                                       # same bound as tests/test_model_gpu.py
     # most rows are untouched by any flip: they agree to fp32 summation order
     row_err = np.abs(z["lg"] - lg).max(-1) / np.abs(lg).max()
     assert (row_err < 1e-5).sum() >= len(row_err) // 3
