@@ -9,136 +9,138 @@
 // with the f16 cache (vec_dot_type of F16, R/ggml/src/ggml-cpu/ggml-cpu.c:260-264), products accumulate in fp32,
 // the soft-max denominator in double (ggml-cpu.c:9122-9129).
 //
-// One 256-thread block per (head, tile of <= 8 tokens).  K rows (256 B at d = 128) are read with 16-byte loads,
-// 16 lanes per cache cell; V^T rows are contiguous in the cell index, read 16 bytes per lane; scores live in LDS.
+// One 256-thread block per (head, tile of <= 8 or 16 tokens, slice of the output dims).  Both products run on the
+// matrix cores (v_mfma_f32_16x16x32_f16: f16 x f16 products are exact in fp32, accumulation in fp32 like the CPU
+// backend's vec_dot_f16): a 16-byte load IS one lane's A fragment (K rows: 8 consecutive head dims of one cell; V^T
+// rows: 8 consecutive cells of one head dim), the B fragment is the f16-rounded q / p row of token lane%16.  Scores
+// live in LDS (fp32), the f16 probabilities in a second LDS image; the soft-max keeps the CPU's double sum.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "kernels.h"
 #include <mutex>
 
 #define WAVE 64
-constexpr int ATT_TT = 8;      // tokens per block
+typedef int      i32x4 __attribute__((ext_vector_type(4)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void h8_to_f(const i32x4 v, float * f) {
-    const __half2 * h = (const __half2 *) &v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const float2 t = __half22float2(h[i]); f[2*i] = t.x; f[2*i + 1] = t.y; }
-}
+__device__ __forceinline__ f16x8 as_h8(const i32x4 v) { return __builtin_bit_cast(f16x8, v); }
 __device__ __forceinline__ float rnd16(float v) { return __half2float(__float2half_rn(v)); }
 
-template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_attn_args a) {
-    extern __shared__ __attribute__((aligned(16))) float sc[];          // [TT][n_kv]
-    __shared__ double shd[4];
-    const int h = blockIdx.x, t0 = blockIdx.y * ATT_TT;
-    const int nt = min(ATT_TT, a.T - t0);
+// LDS image: sc [tt][n_kv + 4] fp32 scores, ph [tt][n_kv + 8] f16 probabilities, red [4][64] float4 partial tiles
+static inline size_t attn_lds_bytes(int n_kv, int tt) { return (size_t) tt * (n_kv + 4) * 4 + (size_t) tt * (n_kv + 8) * 2 + 4 * 64 * 16; }
+
+template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_attn_args a, const int tt) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int n_kv = a.n_kv;
+    const int ldS = n_kv + 4, ldP = n_kv + 8;
+    float    * sc  = (float *) lds;
+    _Float16 * ph  = (_Float16 *)(lds + (size_t) tt * ldS * 4);
+    f32x4    * red = (f32x4 *)(lds + (size_t) tt * ldS * 4 + (size_t) tt * ldP * 2);
+    const int h = blockIdx.x, t0 = blockIdx.y * tt;
+    const int nt = min(tt, a.T - t0);
     const int hk = h / (a.H / a.H_kv);
     const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
-    const int n_kv = a.n_kv;
+    const int col = lane & 15, grp = lane >> 4;            // MFMA maps: A row / B column = lane&15, k = 8*(lane>>4) + j
     const char * kb = (const char *) a.k + (int64_t) hk * a.k_nb2;
     const char * vb = (const char *) a.v + (int64_t) hk * a.v_nb2;
-    constexpr int LPC = D / 8;                 // lanes per cache cell (16 at d = 128)
-    constexpr int CPW = WAVE / LPC;            // cells per wave pass
-    const int sub = lane / LPC, dc = lane % LPC;
+    constexpr int NS = D / 32;                             // MFMA k-steps over the head dim
 
-    // ---- phase 1: scores
-    float qr[ATT_TT][8];
+    // ---- phase 1: scores[cell][t] = K[cell][:] . q[t][:]      (A = 16 cells x 32 dims, B = 32 dims x 16 tokens)
+    f16x8 qf[NS];
 #pragma unroll
-    for (int t = 0; t < ATT_TT; ++t) {
-        if (t < nt) {
-            const float * qp = (const float *)((const char *) a.q + (int64_t)(t0 + t) * a.q_nb1 + (int64_t) h * a.q_nb2) + dc*8;
+    for (int s = 0; s < NS; ++s) {
+        if (col < nt) {
+            const float * qp = (const float *)((const char *) a.q + (int64_t)(t0 + col) * a.q_nb1 + (int64_t) h * a.q_nb2) + 32*s + 8*grp;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qr[t][j] = rnd16(qp[j]);
+            for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16) qp[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qr[t][j] = 0.f;
+            for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16) 0.f;
         }
     }
-    constexpr int KU = 4;                                             // K rows in flight per lane
-    for (int i0 = wave*CPW; i0 < n_kv; i0 += 4*CPW*KU) {
-        i32x4 kv[KU];
+    constexpr int CU = 2;                                  // cell tiles in flight per wave (CU*NS 16-byte loads per lane)
+    for (int c0 = wave*16; c0 < n_kv; c0 += 4*16*CU) {
+        i32x4 kf[CU][NS];
 #pragma unroll
-        for (int u = 0; u < KU; ++u) { const int i = i0 + u*4*CPW + sub; kv[u] = (i < n_kv) ? *(const i32x4 *)(kb + (int64_t) i * a.k_nb1 + dc*16) : (i32x4)(0); }
+        for (int u = 0; u < CU; ++u) {
+            const int cell = c0 + u*64 + col;
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const int i = i0 + u*4*CPW + sub;
-            float kf[8]; h8_to_f(kv[u], kf);
+            for (int s = 0; s < NS; ++s) kf[u][s] = (cell < n_kv) ? *(const i32x4 *)(kb + (int64_t) cell * a.k_nb1 + (32*s + 8*grp) * 2) : (i32x4)(0);
+        }
 #pragma unroll
-            for (int t = 0; t < ATT_TT; ++t) {
-                if (t >= nt) break;
-                float s = 0.f;
+        for (int u = 0; u < CU; ++u) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += kf[j] * qr[t][j];
-#pragma unroll
-                for (int o = LPC/2; o > 0; o >>= 1) s += __shfl_xor(s, o, WAVE);
-                if (dc == 0 && i < n_kv) sc[t*n_kv + i] = s;
-            }
+            for (int s = 0; s < NS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(kf[u][s]), qf[s], c, 0, 0, 0);
+            const int r0 = c0 + u*64 + 4*grp;              // C: column (token) = lane&15, rows (cells) = 4*(lane>>4) + 0..3
+            if (col < nt && r0 < n_kv) *(f32x4 *)(sc + col*ldS + r0) = c;
         }
     }
     __syncthreads();
-    // ---- phase 2: soft-max per token row (one wave per row), probabilities rounded through f16
-    for (int t = wave; t < nt; t += 4) {
-        float * row = sc + t*n_kv;
-        const float * m32 = a.mask_f16 ? nullptr : (const float *)((const char *) a.mask + (int64_t)(t0 + t) * a.mask_nb1);
-        const __half * m16 = a.mask_f16 ? (const __half *)((const char *) a.mask + (int64_t)(t0 + t) * a.mask_nb1) : nullptr;
-        float mx = -INFINITY;
-        for (int i = lane; i < n_kv; i += WAVE) {
-            float v = __fmul_rn(row[i], a.scale);
-            if (a.mask) v = __fadd_rn(v, a.mask_f16 ? __half2float(m16[i]) : m32[i]);
-            row[i] = v; mx = fmaxf(mx, v);
+    // ---- phase 2: soft-max, 16 lanes per token row, probabilities rounded to f16 (the vec_dot_type of the f16 V cache)
+    {
+        const int t = threadIdx.x >> 4, sub = threadIdx.x & 15;
+        if (t < nt) {
+            float * row = sc + t*ldS;
+            _Float16 * prow = ph + t*ldP;
+            const float * m32 = a.mask_f16 ? nullptr : (const float *)((const char *) a.mask + (int64_t)(t0 + t) * a.mask_nb1);
+            const __half * m16 = a.mask_f16 ? (const __half *)((const char *) a.mask + (int64_t)(t0 + t) * a.mask_nb1) : nullptr;
+            float mx = -INFINITY;
+            for (int i = sub; i < n_kv; i += 16) {
+                float v = __fmul_rn(row[i], a.scale);
+                if (a.mask) v = __fadd_rn(v, a.mask_f16 ? __half2float(m16[i]) : m32[i]);
+                row[i] = v; mx = fmaxf(mx, v);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+            double sum = 0.0;
+            for (int i = sub; i < n_kv; i += 16) { const float e = (row[i] == -INFINITY) ? 0.0f : expf(row[i] - mx); row[i] = e; sum += (double) e; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+            const float inv = (float)(1.0 / sum);
+            for (int i = sub; i < n_kv; i += 16) prow[i] = (_Float16)(row[i] * inv);
         }
-#pragma unroll
-        for (int o = WAVE/2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
-        double sum = 0.0;
-        for (int i = lane; i < n_kv; i += WAVE) { const float e = (row[i] == -INFINITY) ? 0.0f : expf(row[i] - mx); row[i] = e; sum += (double) e; }
-#pragma unroll
-        for (int o = WAVE/2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, WAVE);
-        const float inv = (float)(1.0 / sum);
-        for (int i = lane; i < n_kv; i += WAVE) row[i] = rnd16(row[i] * inv);
     }
     __syncthreads();
-    // ---- phase 3: out[d, t] = sum_i V[i, d] * p[t][i]; a wave takes DU output dims per pass (DU independent 16-byte
-    //      V loads in flight), lanes across cells (8 per lane); blockIdx.z splits the output dims between blocks
-    constexpr int DU = 4;
-    const int dper = D / gridDim.z, dbeg = blockIdx.z * dper;
-    for (int d0 = dbeg + wave*DU; d0 < dbeg + dper; d0 += 4*DU) {
-        float acc[DU][ATT_TT];
+    // ---- phase 3: out[t][dd] = sum_i V^T[dd][i] * p[t][i]      (A = 16 head dims x 32 cells, B = 32 cells x 16 tokens)
+    //      blockIdx.z takes TPB of the D/16 output tiles; the 4 waves split (tile, cell range) and reduce through LDS
+    const int tpb = (D/16) / gridDim.z;                    // 1, 2 or 4 tiles per block
+    const int wpt = 4 / tpb;                               // waves sharing one tile
+    const int tile = blockIdx.z * tpb + wave / wpt, part = wave % wpt;
+    const int dd0 = tile * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int VU = 4;                                  // 32-cell chunks in flight
+    for (int i0 = part*32; i0 < n_kv; i0 += wpt*32*VU) {
+        i32x4 vf[VU];
 #pragma unroll
-        for (int u = 0; u < DU; ++u)
-#pragma unroll
-            for (int t = 0; t < ATT_TT; ++t) acc[u][t] = 0.f;
-        for (int i = lane*8; i < n_kv; i += WAVE*8) {
-            i32x4 vv[DU];
-#pragma unroll
-            for (int u = 0; u < DU; ++u) vv[u] = *(const i32x4 *)(vb + (int64_t)(d0 + u) * a.v_nb1 + (int64_t) i * 2);
-#pragma unroll
-            for (int t = 0; t < ATT_TT; ++t) {
-                if (t >= nt) break;
-                const float4 p0 = *(const float4 *)(sc + t*n_kv + i), p1 = *(const float4 *)(sc + t*n_kv + i + 4);
-#pragma unroll
-                for (int u = 0; u < DU; ++u) {
-                    float vf[8]; h8_to_f(vv[u], vf);
-                    acc[u][t] += vf[0]*p0.x + vf[1]*p0.y + vf[2]*p0.z + vf[3]*p0.w + vf[4]*p1.x + vf[5]*p1.y + vf[6]*p1.z + vf[7]*p1.w;
-                }
-            }
+        for (int u = 0; u < VU; ++u) {
+            const int i = i0 + u*wpt*32 + 8*grp;
+            vf[u] = (i < n_kv) ? *(const i32x4 *)(vb + (int64_t)(dd0 + col) * a.v_nb1 + (int64_t) i * 2) : (i32x4)(0);
         }
 #pragma unroll
-        for (int u = 0; u < DU; ++u)
-#pragma unroll
-            for (int t = 0; t < ATT_TT; ++t) {
-                if (t >= nt) break;
-                float v = acc[u][t];
-#pragma unroll
-                for (int o = WAVE/2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-                if (lane == 0) *(float *)((char *) a.out + (int64_t)(d0 + u)*4 + (int64_t) h * a.o_nb1 + (int64_t)(t0 + t) * a.o_nb2) = v;
-            }
+        for (int u = 0; u < VU; ++u) {
+            const int i = i0 + u*wpt*32 + 8*grp;
+            const i32x4 pf = (col < nt && i < n_kv) ? *(const i32x4 *)(ph + col*ldP + i) : (i32x4)(0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(vf[u]), as_h8(pf), acc, 0, 0, 0);
+        }
     }
-    (void) shd;
+    if (wpt > 1) {
+        if (part) red[wave*64 + lane] = acc;
+        __syncthreads();
+        if (part == 0) for (int w = 1; w < wpt; ++w) acc += red[(wave + w)*64 + lane];
+    }
+    if (part == 0 && col < nt) {                           // C: column (token) = lane&15, rows (head dims) = 4*(lane>>4) + 0..3
+        float * o = (float *)((char *) a.out + (int64_t)(dd0 + 4*grp)*4 + (int64_t) h * a.o_nb1 + (int64_t)(t0 + col) * a.o_nb2);
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
 }
+
+static int attn_tokens_per_block(const mi_attn_args & a) { return (a.T > 8 && attn_lds_bytes(a.n_kv, 16) <= 150*1024) ? 16 : 8; }
 
 bool mi_attn_small_supported(const mi_attn_args & a) {
     if (!(a.d == 64 || a.d == 128)) return false;
-    if (a.n_kv % 8 || a.n_kv <= 0 || (size_t) a.n_kv * ATT_TT * 4 > 150*1024) return false;
+    if (a.n_kv % 8 || a.n_kv <= 0 || attn_lds_bytes(a.n_kv, 8) > 150*1024) return false;
     if (a.H % a.H_kv) return false;
     if (((uintptr_t) a.k | (uintptr_t) a.v | (uintptr_t) a.k_nb1 | (uintptr_t) a.k_nb2 | (uintptr_t) a.v_nb1 | (uintptr_t) a.v_nb2) & 15) return false;
     if (((uintptr_t) a.q | (uintptr_t) a.q_nb1 | (uintptr_t) a.q_nb2) & 3) return false;
@@ -146,15 +148,19 @@ bool mi_attn_small_supported(const mi_attn_args & a) {
 }
 
 void mi_op_attn_small(hipStream_t st, const mi_attn_args & a) {
-    const size_t lds = (size_t) a.n_kv * ATT_TT * 4;
-    const int tiles = (a.T + ATT_TT - 1) / ATT_TT;
-    const int dsplit = (a.H * tiles >= 256) ? 1 : ((a.H * tiles >= 128) ? 2 : 4);     // more blocks when heads x tiles under-fill the chip
+    const int tt = attn_tokens_per_block(a);
+    const size_t lds = attn_lds_bytes(a.n_kv, tt);
+    const int tiles = (a.T + tt - 1) / tt;
+    const int ntile = a.d / 16;                                   // output tiles of 16 head dims
+    // more blocks when heads x token tiles under-fill the chip; a block keeps 1, 2 or 4 output tiles
+    int dsplit = (a.H * tiles >= 256) ? ntile/4 : ((a.H * tiles >= 128) ? ntile/2 : ntile);
+    if (dsplit < 1) dsplit = 1;
     const dim3 grid(a.H, tiles, dsplit);
     static std::once_flag once;
     std::call_once(once, [] {
-        HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 152*1024));
-        HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 152*1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
+        HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
     });
-    if (a.d == 128) k_attn_small<128><<<grid, 256, lds, st>>>(a);
-    else            k_attn_small<64><<<grid, 256, lds, st>>>(a);
+    if (a.d == 128) k_attn_small<128><<<grid, 256, lds, st>>>(a, tt);
+    else            k_attn_small<64><<<grid, 256, lds, st>>>(a, tt);
 }
