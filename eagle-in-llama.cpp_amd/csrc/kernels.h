@@ -39,6 +39,12 @@ int  mi_mmvq_max_tokens(int type, int k);
 size_t mi_act_image_bytes(int type, int T, int k);
 void mi_quant_act(hipStream_t st, int type, int T, const act_src & a, int k, char * out);
 void mi_mmvq_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L, mi_act_cache * cache, const void * key);
+// matrix-core variant for K-quants (kernels_mmq.hip); needs L.act.pre (image written by mi_quant_act)
+bool mi_mmq_supported(int type, int T, int k);
+void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L);
+// HIP-event profile hooks around a mat-vec launch (bench.py roofline): begin returns a record index or -1 when off
+int  mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual);
+void mi_prof_end(hipStream_t st, int idx);
 // quantised weight x f32 activations; residual (nullable) is added in the epilogue (fused ADD)
 void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out, mi_act_cache * cache);
 // f16 / f32 / bf16 src0 x f32 src1 (attention K.q, V.p and unquantised weights)

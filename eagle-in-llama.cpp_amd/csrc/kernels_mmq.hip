@@ -1,0 +1,333 @@
+// kernels_mmq.hip -- K-quant weight x int8 activation products for 1..8 tokens on the matrix cores.
+//
+// Same arithmetic as kernels_mmvq.hip (the CPU backend's: Q8_K activations, the integer dot products of
+// ggml_vec_dot_{q4_K,q5_K,q6_K}_q8_K, R/ggml/src/ggml-cpu/ggml-cpu-quants.c), different machine mapping: the dp4a
+// kernel spends ~20 VALU instructions per (row, token, 32 weights), which makes a 6-token tree verification
+// VALU-bound long before HBM is busy.  Here v_mfma_i32_16x16x64_i8 does the integer dots of 16 weight rows against
+// all tokens at once:
+//     B (N = weight rows)  lane (n = lane&15, kq = lane>>4): 16 unpacked quants of row n in k-slots 16kq..16kq+15
+//     A (M = token,class)  lane (i = lane&15, kq): M rows 0..7 = the tokens, M rows 8..15 = the tokens again;
+//                          the two classes are non-zero in DIFFERENT k-slot groups, so one MFMA (K = 64) returns the
+//                          sums over two different sub-blocks separately -- each needs its own scale
+//     C                    lane (n, g = lane>>4), reg r: class g>>1, token 4*(g&1) + r
+// After the MFMA a lane holds, for its row, the sub-block sums of four tokens: the sub-block scale is one integer
+// multiply-add per (row, token), nothing is reduced across lanes (the two classes meet in the split-K reduction),
+// and a wave stores 16 consecutive rows.
+//   * Q4_K / Q5_K: a 16-byte load of qs is two B operands (low / high nibbles = sub-blocks 2g / 2g+1); lanes kq<2 carry
+//     groups g = 0, 1, lanes kq>=2 groups 2, 3 -> 4 MFMAs per super-block.
+//   * Q6_K: 16-element sub-blocks: a B operand holds four of them; two MFMAs with complementary activation masks read it.
+//   * mins (Q4_K/Q5_K) and the -32 offset (Q6_K) are sum_j m_j * bsum_j: one more MFMA against the block sums, which
+//     k_quant_act stores split as 128*h + l (both int8; l = class 0, h = class 1).
+// A 512/1024-thread block owns 16 rows; its waves split the super-blocks of the row (split-K) and reduce through LDS in
+// a fixed order.  The quantised activation image (mi_quant_act) is copied into LDS once per block.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "mmvq_device.h"
+#include <mutex>
+#include <unordered_map>
+
+typedef float f32x4  __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 mfma_i8(const i32x4 a, const i32x4 b) {
+    const i32x4 z = {0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, z, 0, 0, 0);
+}
+__device__ __forceinline__ int byte_of(uint32_t v, int j) { return (int)((v >> (8*j)) & 0xffu); }
+__device__ __forceinline__ int sbyte_of(uint32_t v, int j) { return (int)(int8_t)((v >> (8*j)) & 0xffu); }
+
+// ---- what a lane (n = lane&15, kq = lane>>4) keeps of one (row, super-block): loads only
+template <int TYPE> struct mq_frag;
+template <> struct mq_frag<GGML_TYPE_Q4_K> {          // qs bytes [32*gA + 16*(kq&1), +16) for gA = (kq>>1)*2 + {0, 1}
+    static constexpr int BLK = 144;
+    i32x4 hdr, qs[2];
+    __device__ __forceinline__ void load(const char * b, int kq) {
+        hdr = ld16(b);
+        qs[0] = ld16(b + 16 + 64*(kq >> 1) + 16*(kq & 1)); qs[1] = ld16(b + 16 + 64*(kq >> 1) + 32 + 16*(kq & 1));
+    }
+};
+template <> struct mq_frag<GGML_TYPE_Q5_K> {
+    static constexpr int BLK = 176;
+    i32x4 hdr, qh, qs[2];
+    __device__ __forceinline__ void load(const char * b, int kq) {
+        hdr = ld16(b); qh = ld16(b + 16 + 16*(kq & 1));
+        qs[0] = ld16(b + 48 + 64*(kq >> 1) + 16*(kq & 1)); qs[1] = ld16(b + 48 + 64*(kq >> 1) + 32 + 16*(kq & 1));
+    }
+};
+template <> struct mq_frag<GGML_TYPE_Q6_K> {          // kq = 2*qb + lh: ql bytes [64*nn + 32*qb + 16*lh, +16), qh bytes [32*nn + 16*lh, +16), nn = 0, 1
+    static constexpr int BLK = 210;
+    i32x4 ql[2], qh[2], sc; int dh;
+    __device__ __forceinline__ void load(const char * b, int kq) {
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) { ql[nn] = ld16(b + 64*nn + 32*(kq >> 1) + 16*(kq & 1)); qh[nn] = ld16(b + 128 + 32*nn + 16*(kq & 1)); }
+        sc = ld16(b + 192);
+        uint16_t d; __builtin_memcpy(&d, b + 208, 2); dh = d;
+    }
+};
+
+// LDS view of the activation image
+struct mq_act { const int8_t * q; int ldq; const float * d; const char * rec; int nsb; int T; };
+
+// ---- one super-block of 16 rows x T tokens.  The M dimension of the MFMA carries (token, class): M rows 0..7 are the
+// tokens against the k-slots of one sub-block, M rows 8..15 the same tokens against another sub-block, the activations
+// being zero in the k-slots of the other class.  C lane (n, g = lane>>4), reg r: M row 4g + r, i.e. class g>>1, token
+// 4*(g&1) + r: acc[r] is this lane's share (its class) of out[row n][token 4*(g&1) + r]; classes are added in the reduction.
+template <int TYPE> __device__ __forceinline__ void mq_process(const mq_frag<TYPE> & f, const mq_act & A, int sb, int lane, float (&acc)[4]);
+
+template <int TYPE> __device__ __forceinline__ void mq_process_q45(const mq_frag<TYPE> & f, const mq_act & A, int sb, int lane, float (&acc)[4]) {
+    const int i = lane & 15, kq = lane >> 4, g = kq;
+    const uint32_t u0 = f.hdr.y, u1 = f.hdr.z, u2 = f.hdr.w;             // get_scale_min_k4 for all eight sub-blocks (ggml-quants.c:631-638)
+    const uint32_t s_lo = u0 & 0x3f3f3f3fu, s_hi = (u2 & 0x0f0f0f0fu) | ((u0 >> 2) & 0x30303030u);
+    const uint32_t m_lo = u1 & 0x3f3f3f3fu, m_hi = ((u2 >> 4) & 0x0f0f0f0fu) | ((u1 >> 2) & 0x30303030u);
+    const float dw = h2f((uint16_t)(f.hdr.x & 0xffff)), mw = h2f((uint16_t)((uint32_t) f.hdr.x >> 16));
+    // B: lanes kq<2 hold group gA = {0,1}, lanes kq>=2 group gA + 2; k-slots 16*(kq&1).. of the 32-element sub-block.
+    // A: M row i<8 = token i, active in k-slots kq<2 (class 0: sub-blocks 2gA, 2gA+1); M row i>=8 = token i-8, active in kq>=2 (class 1)
+    const int  tok_a = i & 7, cls_a = i >> 3;
+    const bool av = tok_a < A.T && cls_a == (kq >> 1);
+    const int8_t * arow = A.q + tok_a*A.ldq + sb*256 + 128*cls_a + 16*(kq & 1);
+    const uint32_t sw = (g >> 1) ? s_hi : s_lo;                           // scales of this lane's class: sub-blocks 4*cls + 0..3
+    int isum[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int ga = 0; ga < 2; ++ga) {
+        i32x4 blo = f.qs[ga] & 0x0F0F0F0F, bhi = (f.qs[ga] >> 4) & 0x0F0F0F0F;
+        if constexpr (TYPE == GGML_TYPE_Q5_K) {                           // bit 2g' / 2g'+1 of qh, g' = 2*(kq>>1) + ga
+            const i32x4 hb = (kq >> 1) ? (f.qh >> 4) : f.qh;
+            blo |= ((hb >> (2*ga)) & 0x01010101) << 4; bhi |= ((hb >> (2*ga + 1)) & 0x01010101) << 4;
+        }
+        const i32x4 alo = av ? *(const i32x4 *)(arow + 64*ga) : (i32x4)(0);
+        const i32x4 ahi = av ? *(const i32x4 *)(arow + 64*ga + 32) : (i32x4)(0);
+        const i32x4 c0 = mfma_i8(alo, blo);
+        const i32x4 c1 = mfma_i8(ahi, bhi);
+        const int s0 = byte_of(sw, 2*ga), s1 = byte_of(sw, 2*ga + 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) isum[r] += __mul24(s0, c0[r]) + __mul24(s1, c1[r]);
+    }
+    // mins: sum_j m_j * bsum32_j with the sums split as 128*h + l: class 0 = l parts, class 1 = h parts, both in k-slots kq = 0
+    const bool mv = kq == 0 && tok_a < A.T;
+    const i32x4 am = mv ? *(const i32x4 *)(A.rec + (tok_a*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
+    i32x4 bm = {0, 0, 0, 0};
+    if (kq == 0) { bm.x = (int) m_lo; bm.y = (int) m_hi; }
+    const i32x4 cm = mfma_i8(am, bm);
+    const float mscale = (g >> 1) ? 128.f : 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tok = 4*(g & 1) + r;
+        const float dy = tok < A.T ? A.d[tok*A.nsb + sb] : 0.f;
+        acc[r] += (dw*dy)*(float) isum[r] - ((mw*dy)*mscale)*(float) cm[r];
+    }
+}
+template <> __device__ __forceinline__ void mq_process<GGML_TYPE_Q4_K>(const mq_frag<GGML_TYPE_Q4_K> & f, const mq_act & A, int sb, int lane, float (&acc)[4]) { mq_process_q45<GGML_TYPE_Q4_K>(f, A, sb, lane, acc); }
+template <> __device__ __forceinline__ void mq_process<GGML_TYPE_Q5_K>(const mq_frag<GGML_TYPE_Q5_K> & f, const mq_act & A, int sb, int lane, float (&acc)[4]) { mq_process_q45<GGML_TYPE_Q5_K>(f, A, sb, lane, acc); }
+
+template <> __device__ __forceinline__ void mq_process<GGML_TYPE_Q6_K>(const mq_frag<GGML_TYPE_Q6_K> & f, const mq_act & A, int sb, int lane, float (&acc)[4]) {
+    const int i = lane & 15, kq = lane >> 4, g = kq, qb = kq >> 1, lh = kq & 1;
+    // element 128nn + 32q + l (l = 16lh + byte): ql[64nn + 32(q&1) + l] nibble q>>1, qh[32nn + l] bits 2q, 2q+1; 16-element
+    // sub-block s = 8nn + 2q + lh.  B operand (nn, nib): lane kq holds q = qb + 2nib.  Two MFMAs use it: pass p activates
+    // the k-slots of the lanes with qb == p; in a pass, class (M rows 0..7 | 8..15) = lh.
+    const int  tok_a = i & 7, cls_a = i >> 3;
+    const bool tv = tok_a < A.T && cls_a == lh;
+    const int8_t * arow = A.q + tok_a*A.ldq + sb*256 + 16*lh;
+    int isum[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int nib = 0; nib < 2; ++nib) {
+            const i32x4 nb = nib ? ((f.ql[nn] >> 4) & 0x0F0F0F0F) : (f.ql[nn] & 0x0F0F0F0F);
+            const i32x4 hb = qb ? (f.qh[nn] >> 2) : f.qh[nn];               // bits 2q.. with q = qb + 2nib
+            const i32x4 b = nb | (((hb >> (4*nib)) & 0x03030303) << 4);
+            const uint32_t sw = (uint32_t) f.sc[2*nn + nib];                // scales[8nn + 4nib + 0..3] = sub-blocks 8nn + 2(2nib + p) + lh, p = 0, 1
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int q = p + 2*nib;
+                const i32x4 a = (tv && qb == p) ? *(const i32x4 *)(arow + 128*nn + 32*q) : (i32x4)(0);
+                const i32x4 c = mfma_i8(a, b);
+                // C lane g: class g>>1 = lh of the sub-block -> scale of sub-block 8nn + 2q + (g>>1)
+                const int sc = (g >> 1) ? sbyte_of(sw, 2*p + 1) : sbyte_of(sw, 2*p);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) isum[r] += __mul24(sc, c[r]);
+            }
+        }
+    // -32 offset: 32 * sum_j scale_j * bsum16_j (class 0 = l parts, class 1 = h parts of the split sums)
+    const bool mv = kq == 0 && tok_a < A.T;
+    const i32x4 am = mv ? *(const i32x4 *)(A.rec + (tok_a*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
+    const i32x4 bm = kq == 0 ? f.sc : (i32x4)(0);
+    const i32x4 cm = mfma_i8(am, bm);
+    const float dw = h2f((uint16_t) f.dh);
+    const int mscale = (g >> 1) ? 128*32 : 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tok = 4*(g & 1) + r;
+        const float dy = tok < A.T ? A.d[tok*A.nsb + sb] : 0.f;
+        acc[r] += (dw*dy)*(float)(isum[r] - mscale*cm[r]);
+    }
+}
+
+static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual) {
+    const size_t nsb = k/256;
+    return (size_t) T*(k + 16) + (((size_t) T*nsb*4 + 15) & ~(size_t) 15) + (size_t) T*nsb*32 + (size_t) NW*64*16*(dual ? 2 : 1);
+}
+
+template <int TYPE, bool DUAL, int NW>
+__global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int k = L.k, nsb = k/256, ldq = k + 16;
+    int8_t * lq  = (int8_t *) smem;
+    float  * ldy = (float *)(smem + (size_t) T*ldq);
+    char   * lrec = (char *) ldy + (((size_t) T*nsb*4 + 15) & ~(size_t) 15);
+    f32x4  * red = (f32x4 *)(lrec + (size_t) T*nsb*32);
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    const int kq = lane >> 4;
+    constexpr int BLK = mq_frag<TYPE>::BLK;
+    constexpr int NM = DUAL ? 2 : 1;
+
+    const int c0 = (L.m[0].rows + 15) / 16;
+    const int c1 = (!DUAL && L.n_mat > 1) ? (L.m[1].rows + 15) / 16 : 0;
+    const int c2 = (!DUAL && L.n_mat > 2) ? (L.m[2].rows + 15) / 16 : 0;
+    const int total = c0 + c1 + c2;
+    const int nu = wave < nsb ? ((nsb - wave + NW - 1) / NW) * NM : 0;    // (matrix, super-block) units of this wave per row group
+
+    const char * rp[NM];
+    auto set_rows = [&](int g, int & mi, int & row0) {
+        if (g < c0) { mi = 0; row0 = g*16; } else if (g < c0 + c1) { mi = 1; row0 = (g - c0)*16; } else { mi = 2; row0 = (g - c0 - c1)*16; }
+        rp[0] = L.m[mi].W + (size_t) min(row0 + (lane & 15), L.m[mi].rows - 1) * L.m[mi].row_bytes;
+        if (DUAL) rp[NM - 1] = L.m[1].W + (size_t) min(row0 + (lane & 15), L.m[1].rows - 1) * L.m[1].row_bytes;
+    };
+    auto unit_ptr = [&](int u) -> const char * { return DUAL ? rp[u & 1] + (size_t)(wave + (u >> 1)*NW) * BLK : rp[0] + (size_t)(wave + u*NW) * BLK; };
+
+    mq_frag<TYPE> fa, fb;
+    int grp = blockIdx.x, mi = 0, row0 = 0;
+    if (grp < total) { set_rows(grp, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq); }      // in flight across the prologue
+    {   // activation image (HBM scratch, written by k_quant_act) -> LDS; token rows padded by 16 bytes against bank conflicts
+        const int nthr = NW*WAVE, n16row = k/16;
+        const i32x4 * src = (const i32x4 *) L.act.pre;
+        for (int c = threadIdx.x; c < T*n16row; c += nthr) { const int t = c / n16row, o = c - t*n16row; *(i32x4 *)(lq + (size_t) t*ldq + o*16) = src[c]; }
+        const float * sd = (const float *)(L.act.pre + (size_t) T*k);
+        for (int c = threadIdx.x; c < T*nsb; c += nthr) ldy[c] = sd[c];
+        const char * sr = L.act.pre + act_img_bytes(true, T, k) + (TYPE == GGML_TYPE_Q6_K ? (size_t) T*nsb*32 : 0);     // 4-byte aligned only
+        for (int c = threadIdx.x; c < T*nsb*2; c += nthr) ((i32x4 *) lrec)[c] = ld16(sr + (size_t) c*16);
+    }
+    __syncthreads();
+    const mq_act A = { lq, ldq, ldy, lrec, nsb, T };
+
+    while (grp < total) {
+        float acc[NM][4];
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+        for (int u = 0; u < nu; u += 2) {
+            if (u + 1 < nu) fb.load(unit_ptr(u + 1), kq);
+            mq_process<TYPE>(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[DUAL ? (u & 1) : 0]);
+            if (u + 1 >= nu) break;
+            if (u + 2 < nu) fa.load(unit_ptr(u + 2), kq);
+            mq_process<TYPE>(fb, A, DUAL ? wave + ((u + 1) >> 1)*NW : wave + (u + 1)*NW, lane, acc[DUAL ? ((u + 1) & 1) : 0]);
+        }
+        // next group's first loads go out before this group's reduction / epilogue
+        const int cmi = mi, crow0 = row0, gn = grp + gridDim.x;
+        if (gn < total) { set_rows(gn, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq); }
+        // ---- split-K reduction in a fixed order (wave 0 adds the partial tiles of waves 0..NW-1)
+        __syncthreads();                                                   // wave 0 is done with the previous group's tiles
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { const f32x4 v = { acc[m][0], acc[m][1], acc[m][2], acc[m][3] }; red[(m*NW + wave)*WAVE + lane] = v; }
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 v[NM];                                                    // both classes (lanes l, l^32) of all waves: every lane ends with the full sums
+#pragma unroll
+            for (int m = 0; m < NM; ++m) { v[m] = red[(m*NW)*WAVE + lane] + red[(m*NW)*WAVE + (lane ^ 32)]; for (int w = 1; w < NW; ++w) v[m] += red[(m*NW + w)*WAVE + lane] + red[(m*NW + w)*WAVE + (lane ^ 32)]; }
+            const mmvq_mat & M = L.m[cmi];
+            const int row = crow0 + (lane & 15), tg = kq & 1;
+            const bool in = row < M.rows && kq < 2;
+            if (DUAL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int tok = 4*tg + r; if (in && tok < T) { const float g0 = v[0][r]; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = (g0 / (1.0f + expf(-g0))) * v[NM - 1][r]; } }
+            } else if (M.epi == EPI_F32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int tok = 4*tg + r; if (in && tok < T) { float o = v[0][r]; if (M.res) o += M.res[(size_t) tok*M.r_tok + row]; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = o; } }
+            } else if (M.epi == EPI_F16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int tok = 4*tg + r; if (in && tok < T) *(__half *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = __float2half_rn(v[0][r]); }
+            } else {   // RoPE (mode NORM) on the row pair held by lanes (2p, 2p+1); theta by the reference's float recurrence (ggml_rope_cache_init)
+                float pr[4], th[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pr[r] = dpp_f<DPP_XOR1>(v[0][r]); const int tok = 4*tg + r; th[r] = tok < T ? (float) L.rope.pos[tok] : 0.f; }
+                const int ip = (row % L.rope.head_dim) >> 1;
+                for (int j = 0; j < ip; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) th[r] *= L.rope.theta_scale;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tok = 4*tg + r;
+                    if (!(in && tok < T)) continue;
+                    const float a = L.rope.freq_scale * th[r];
+                    const float c = cosf(a) * L.rope.attn_factor, sn = sinf(a) * L.rope.attn_factor;
+                    const float x0 = (row & 1) ? pr[r] : v[0][r], x1 = (row & 1) ? v[0][r] : pr[r];
+                    const float y = (row & 1) ? x0*sn + x1*c : x0*c - x1*sn;
+                    if (M.epi == EPI_ROPE_F32) *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = y;
+                    else                       *(__half *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = __float2half_rn(y);
+                }
+            }
+        }
+        grp = gn;
+    }
+}
+
+// ---------------------------------------------------------------- host side
+static std::mutex g_mu;
+static std::unordered_map<const void *, int> g_occ;         // blocks per CU, per kernel instantiation (queried with the largest LDS seen)
+static std::unordered_map<const void *, size_t> g_lds;
+
+static int blocks_per_cu(const void * fn, int threads, size_t lds) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_lds.find(fn);
+    if (it == g_lds.end() || it->second < lds) {
+        if (lds > 48*1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+        int nb = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds));
+        if (nb < 1) nb = 1;
+        g_lds[fn] = lds; g_occ[fn] = nb;
+    }
+    return g_occ[fn];
+}
+
+template <int TYPE, bool DUAL, int NW> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
+    const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL);
+    MI_ASSERT(lds <= 160*1024 && L.act.pre);
+    int total = 0;
+    if (DUAL) total = (L.m[0].rows + 15) / 16;
+    else for (int i = 0; i < L.n_mat; ++i) total += (L.m[i].rows + 15) / 16;
+    if (total < 1) return;
+    auto fn = k_mmq<TYPE, DUAL, NW>;
+    int per_cu = blocks_per_cu((const void *) fn, NW*WAVE, lds);
+    if (per_cu > 4) per_cu = 4;
+    const int grid = total < 256*per_cu ? total : 256*per_cu;
+    const int pi = mi_prof_begin(st, L, T, DUAL);
+    fn<<<grid, NW*WAVE, lds, st>>>(L, T);
+    mi_prof_end(st, pi);
+}
+template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmvq_launch & L) {
+    int total = 0;
+    for (int i = 0; i < (L.swiglu ? 1 : L.n_mat); ++i) total += (L.m[i].rows + 15) / 16;
+    // few row groups and a long k: 16 waves per group so that every wave still has <= ~3 super-blocks in sequence
+    const bool wide = total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu) <= 160*1024;
+    if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16>(st, T, L); else mmq_launch_one<TYPE, true, 8>(st, T, L); }
+    else          { if (wide) mmq_launch_one<TYPE, false, 16>(st, T, L); else mmq_launch_one<TYPE, false, 8>(st, T, L); }
+}
+
+bool mi_mmq_supported(int type, int T, int k) {
+    if (!(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K)) return false;
+    if (T < 1 || T > 8 || k % 256) return false;
+    return mmq_lds_bytes(T, k, 8, true) <= 156*1024;
+}
+int mi_mmq_max_tokens(int type, int k) {
+    int t = 8;
+    while (t > 0 && !mi_mmq_supported(type, t, k)) --t;
+    return t;
+}
+void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L) {
+    switch (type) {
+        case GGML_TYPE_Q4_K: mmq_launch_type<GGML_TYPE_Q4_K>(st, T, L); break;
+        case GGML_TYPE_Q5_K: mmq_launch_type<GGML_TYPE_Q5_K>(st, T, L); break;
+        case GGML_TYPE_Q6_K: mmq_launch_type<GGML_TYPE_Q6_K>(st, T, L); break;
+        default: MI_ABORT("mmq: unsupported weight type %d", type);
+    }
+}

@@ -24,162 +24,13 @@
 #include <hip/hip_fp16.h>
 #include "kernels.h"
 #include <mutex>
+#include <unordered_map>
 #include <unordered_set>
+#include <cstdlib>
 #include <vector>
 
-#define WAVE 64
-typedef int   i32x4 __attribute__((ext_vector_type(4)));
+#include "mmvq_device.h"
 
-__device__ __forceinline__ i32x4 ld16(const void * p) { i32x4 v; __builtin_memcpy(&v, p, 16); return v; }   // any alignment
-__device__ __forceinline__ float h2f(uint16_t h) { return __half2float(__ushort_as_half(h)); }
-__device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdgcn_sdot4(a, b, c, false); }
-__device__ __forceinline__ int dot16(i32x4 a, i32x4 b) {
-    int s = dot4(a.x, b.x, 0); s = dot4(a.y, b.y, s); s = dot4(a.z, b.z, s); return dot4(a.w, b.w, s);
-}
-// ---- wave64 reductions on the DPP path (no LDS traffic, unlike ds_bpermute-based __shfl):
-// quad_perm xor1 / xor2, row_half_mirror, row_mirror fold a 16-lane row; the four row sums are combined through readlane.
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
-template <int CTRL> __device__ __forceinline__ int   dpp_i(int v)   { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-#define DPP_XOR1 0xB1      /* quad_perm [1,0,3,2] */
-#define DPP_XOR2 0x4E      /* quad_perm [2,3,0,1] */
-#define DPP_HMIR 0x141     /* row_half_mirror: lane i <-> 7-i  (acts as xor 4 once quads are uniform) */
-#define DPP_MIR  0x140     /* row_mirror:      lane i <-> 15-i (acts as xor 8 once half rows are uniform) */
-__device__ __forceinline__ float rdl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }   // readlane is an int builtin: bit-cast, never convert
-__device__ __forceinline__ float row_sum_f(float v) { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HMIR>(v); v += dpp_f<DPP_MIR>(v); return v; }
-__device__ __forceinline__ float wave_sum_f(float v) {        // result in every lane
-    v = row_sum_f(v);
-    return (rdl_f(v, 0) + rdl_f(v, 16)) + (rdl_f(v, 32) + rdl_f(v, 48));
-}
-__device__ __forceinline__ float row_max_f(float v) { v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_HMIR>(v)); v = fmaxf(v, dpp_f<DPP_MIR>(v)); return v; }
-__device__ __forceinline__ float wave_max_f(float v) {
-    v = row_max_f(v);
-    return fmaxf(fmaxf(rdl_f(v, 0), rdl_f(v, 16)), fmaxf(rdl_f(v, 32), rdl_f(v, 48)));
-}
-__device__ __forceinline__ int wave_min_i(int v) {
-    v = min(v, dpp_i<DPP_XOR1>(v)); v = min(v, dpp_i<DPP_XOR2>(v)); v = min(v, dpp_i<DPP_HMIR>(v)); v = min(v, dpp_i<DPP_MIR>(v));
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-    int2 p = *(int2 *) &v;
-#define DSTEP(C) { int2 q; q.x = dpp_i<C>(p.x); q.y = dpp_i<C>(p.y); v += *(double *) &q; p = *(int2 *) &v; }
-    DSTEP(DPP_XOR1) DSTEP(DPP_XOR2) DSTEP(DPP_HMIR) DSTEP(DPP_MIR)
-#undef DSTEP
-    double r = 0.0;
-#pragma unroll
-    for (int l = 0; l < 64; l += 16) { int2 q; q.x = __builtin_amdgcn_readlane(p.x, l); q.y = __builtin_amdgcn_readlane(p.y, l); r += *(double *) &q; }
-    return r;
-}
-
-// LDS image of the quantised activations
-__host__ __device__ static inline size_t act_img_bytes(bool ktype, int T, int k) {
-    return ktype ? (size_t) T*k + (size_t) T*(k/256)*4 + (size_t) T*(k/16)*2 : (size_t) T*k + (size_t) T*(k/32)*4;
-}
-static inline size_t act_lds_bytes(bool ktype, int T, int k) {
-    return ktype ? (size_t) T*k + (size_t) T*(k/256)*4 + (size_t) T*(k/16)*2 : (size_t) T*k + (size_t) T*(k/32)*4;
-}
-
-// ---------------------------------------------------------------- prologue: (rms_norm * w) -> quantise X[T][k] into LDS
-// Activation source of a launch (struct act_src, kernels.h).  With `norm` the block first recomputes RMS_NORM
-// (+ MUL by the norm weight) of every token row itself -- sum of squares in double exactly like
-// ggml_compute_forward_rms_norm_f32 -- so the normalised fp32 tensor never goes to HBM and the separate norm launch
-// disappears.
-template <int T, int NW> __device__ __forceinline__ void row_scales(const act_src & a, int k, float * sc /*LDS [T]*/, double * red /*LDS [NW][T]*/) {
-    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
-    double s[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) s[t] = 0.0;
-    for (int i = threadIdx.x*4; i < k; i += NW*WAVE*4) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const float4 v = *(const float4 *)(a.X + t*a.xs + i);
-            s[t] += (double)(v.x*v.x); s[t] += (double)(v.y*v.y); s[t] += (double)(v.z*v.z); s[t] += (double)(v.w*v.w);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < T; ++t) { const double r = wave_sum_d(s[t]); if (lane == 0) red[wave*T + t] = r; }
-    __syncthreads();
-    if (threadIdx.x < T) { double tot = 0.0; for (int w = 0; w < NW; ++w) tot += red[w*T + threadIdx.x]; const float mean = (float)(tot / (double) k); sc[threadIdx.x] = 1.0f / sqrtf(mean + a.eps); }
-    __syncthreads();
-}
-__device__ __forceinline__ float4 fetch4(const act_src & a, const float * sc, int t, int e) {
-    float4 v = *(const float4 *)(a.X + t*a.xs + e);
-    if (a.norm) {
-        const float s = sc[t];
-        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-        if (a.norm_w) { const float4 w = *(const float4 *)(a.norm_w + e); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
-    }
-    return v;
-}
-// Q8_K rule: the scale comes from the FIRST element of largest magnitude, iscale = -127/max,
-// q = min(127, rne(iscale*x)), d = 1/iscale, bsums over groups of 16.  One wave = one 256-element super-block;
-// loads for PB super-blocks are issued before the first reduction so their latencies overlap.
-template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, short * bs, int ubeg, int ustr) {
-    const int lane = threadIdx.x % WAVE;
-    const int nsb = k / 256, nu = T*nsb;
-    constexpr int PB = 4;
-    for (int u0 = ubeg; u0 < nu; u0 += ustr*PB) {
-        float4 vv[PB];
-#pragma unroll
-        for (int p = 0; p < PB; ++p) { const int u = u0 + p*ustr; if (u < nu) { const int t = u / nsb, sb = u - t*nsb; vv[p] = fetch4(a, sc, t, sb*256 + lane*4); } }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int u = u0 + p*ustr;
-            if (u >= nu) break;
-            const int t = u / nsb, sb = u - t*nsb;
-            const float xv[4] = { vv[p].x, vv[p].y, vv[p].z, vv[p].w };
-            float amax = 0.0f; int first = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float ax = fabsf(xv[j]); if (ax > amax) { amax = ax; first = j; } }
-            const float wmax = wave_max_f(amax);
-            const int key = wave_min_i((amax == wmax) ? (lane*4 + first) : (1 << 20));     // lowest index holding the maximum
-            const float cand = (first == 0) ? xv[0] : (first == 1) ? xv[1] : (first == 2) ? xv[2] : xv[3];
-            const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand), (key >> 2) & 63));
-            int packed = 0; int s = 0; float dd = 0.0f;
-            if (wmax != 0.0f) {
-                const float iscale = -127.f / mx;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { int qi = __float2int_rn(iscale * xv[j]); qi = min(127, qi); s += qi; packed |= (qi & 0xff) << (8*j); }
-                dd = 1.0f / iscale;
-            }
-            *(int *)(q + t*k + sb*256 + lane*4) = packed;
-            s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s);
-            if ((lane & 3) == 0) bs[t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
-            if (lane == 0) d[t*nsb + sb] = dd;
-        }
-    }
-}
-// Q8_0 rule: d = amax/127, id = 1/d, q = roundf(x*id) (half away from zero), d stored through fp16.
-__device__ __forceinline__ void q80_unit(const float4 v, int8_t * qdst, float * ddst, int lane, bool write) {
-    const float xv[4] = { v.x, v.y, v.z, v.w };
-    float amax = fmaxf(fmaxf(fabsf(xv[0]), fabsf(xv[1])), fmaxf(fabsf(xv[2]), fabsf(xv[3])));
-    amax = fmaxf(amax, dpp_f<DPP_XOR1>(amax)); amax = fmaxf(amax, dpp_f<DPP_XOR2>(amax)); amax = fmaxf(amax, dpp_f<DPP_HMIR>(amax));   // 8 lanes = one block of 32
-    const float dd = amax / 127.f;
-    const float id = dd ? 1.0f/dd : 0.0f;
-    int packed = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int qi = (int) roundf(xv[j]*id); packed |= (qi & 0xff) << (8*j); }
-    if (write) { *(int *) qdst = packed; if ((lane & 7) == 0) *ddst = __half2float(__float2half_rn(dd)); }
-}
-template <int T, int NW> __device__ __forceinline__ void quant_q80_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, int ubeg, int ustr) {
-    const int lane = threadIdx.x % WAVE;
-    const int nch = (k + 255) / 256, nb = k / 32, nu = T*nch;       // a chunk = 256 elements = 8 blocks of 32 (last one may be ragged)
-    constexpr int PB = 4;
-    for (int u0 = ubeg; u0 < nu; u0 += ustr*PB) {
-        float4 vv[PB];
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int u = u0 + p*ustr; vv[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < nu) { const int t = u / nch, ch = u - t*nch, e = ch*256 + lane*4; if (e < k) vv[p] = fetch4(a, sc, t, e); }
-        }
-#pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            const int u = u0 + p*ustr;
-            if (u >= nu) break;
-            const int t = u / nch, ch = u - t*nch, e = ch*256 + lane*4;
-            q80_unit(vv[p], q + t*k + e, d + t*nb + e/32, lane, e < k);
-        }
-    }
-}
 
 // ---------------------------------------------------------------- per-type weight fragments
 // A fragment is what one lane owns of one weight row for one k-step: a 16-byte slice of quants plus the scales that
@@ -488,7 +339,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_quant_act(const act_src a, int k, c
     float  * d = (float *)(out + T*k);
     short  * bs = (short *)((char *) d + T*(KQ ? k/256 : k/32)*4);
     const int wave = threadIdx.x / WAVE;
-    if (KQ) quant_q8K_to_lds<T, NW>(a, sc, k, q, d, bs, blockIdx.x*NW + wave, gridDim.x*NW);
+    if (KQ) quant_q8K_to_lds<T, NW>(a, sc, k, q, d, bs, blockIdx.x*NW + wave, gridDim.x*NW, out + act_img_bytes(true, T, k));
     else    quant_q80_to_lds<T, NW>(a, sc, k, q, d, blockIdx.x*NW + wave, gridDim.x*NW);
 }
 template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src & a, int k, char * out) {
@@ -501,7 +352,7 @@ template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src 
         default: MI_ABORT("quant_act: T=%d", T);
     }
 }
-size_t mi_act_image_bytes(int type, int T, int k) { return (act_img_bytes(mi_traits(type).blck == 256, T, k) + 255) & ~(size_t) 255; }
+size_t mi_act_image_bytes(int type, int T, int k) { return (act_img_bytes_full(mi_traits(type).blck == 256, T, k) + 255) & ~(size_t) 255; }
 void mi_quant_act(hipStream_t st, int type, int T, const act_src & a, int k, char * out) {
     if (mi_traits(type).blck == 256) quant_act_T<true>(st, T, a, k, out); else quant_act_T<false>(st, T, a, k, out);
 }
@@ -509,6 +360,19 @@ void mi_quant_act(hipStream_t st, int type, int T, const act_src & a, int k, cha
 // ---------------------------------------------------------------- host side
 static std::mutex g_attr_mu;
 static std::unordered_set<const void *> g_attr_done;
+static std::unordered_map<const void *, std::pair<size_t, int>> g_occ;     // kernel -> (largest LDS asked for, resident blocks per CU at that size)
+static int occupancy_blocks(const void * fn, int threads, size_t lds) {
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    auto it = g_occ.find(fn);
+    if (it == g_occ.end() || it->second.first < lds) {
+        int nb = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds));
+        if (nb < 1) nb = 1;
+        g_occ[fn] = { lds, nb };
+        return nb;
+    }
+    return it->second.second;
+}
 static void ensure_lds_attr(const void * fn, size_t bytes) {
     if (bytes <= 48*1024) return;
     std::lock_guard<std::mutex> lk(g_attr_mu);
@@ -549,6 +413,20 @@ static double launch_bytes(const mmvq_launch & L, int T, bool dual) {
 
 static inline size_t lds_total(bool ktype, int T, int k, int NW) { return act_lds_bytes(ktype, T, k) + 8 + (size_t) NW*T*8 + (size_t) T*4 + 16; }
 
+// profile hooks shared with kernels_mmq.hip: returns a record index (or -1 when profiling is off)
+int mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual) {
+    if (!g_prof_on) return -1;
+    prof_rec r; HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b)); r.bytes = launch_bytes(L, T, dual);
+    HIP_CHECK(hipEventRecord(r.a, st));
+    std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(r);
+    return (int) g_prof.size() - 1;
+}
+void mi_prof_end(hipStream_t st, int idx) {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx < (int) g_prof.size()) HIP_CHECK(hipEventRecord(g_prof[idx].b, st));
+}
+
 template <int TYPE, int T, int NW, bool DUAL, bool PRE>
 static void launch_one(hipStream_t st, const mmvq_launch & L) {
     const size_t lds = lds_total(act_kind<TYPE>::K, T, L.k, NW);
@@ -558,25 +436,18 @@ static void launch_one(hipStream_t st, const mmvq_launch & L) {
     if (DUAL) total = (L.m[0].rows + MMVQ_R - 1) / MMVQ_R;
     else for (int i = 0; i < L.n_mat; ++i) total += (L.m[i].rows + MMVQ_R - 1) / MMVQ_R;
     // Few, fat, persistent blocks: every block pays the activation prologue once, so the grid is sized to the
-    // chip (two 512-thread blocks per CU when LDS allows), not to the row count; waves stride over row groups.
-    int blocks_cu = (int) ((160*1024) / (lds + 512));
+    // chip (as many 512-thread blocks per CU as registers and LDS allow), not to the row count; waves stride over row groups.
+    auto fn = k_mmvq<TYPE, T, NW, DUAL, PRE>;
+    ensure_lds_attr((const void *) fn, lds);
+    int blocks_cu = occupancy_blocks((const void *) fn, NW*WAVE, lds);
     if (blocks_cu > 2) blocks_cu = 2;
-    if (blocks_cu < 1) blocks_cu = 1;
     int grid = (total + NW - 1) / NW;
     const int cap = 256 * blocks_cu;
     if (grid > cap) grid = cap;
     if (grid < 1) return;
-    auto fn = k_mmvq<TYPE, T, NW, DUAL, PRE>;
-    ensure_lds_attr((const void *) fn, lds);
-    if (g_prof_on) {
-        prof_rec r; HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b)); r.bytes = launch_bytes(L, T, DUAL);
-        HIP_CHECK(hipEventRecord(r.a, st));
-        fn<<<grid, NW*WAVE, lds, st>>>(L);
-        HIP_CHECK(hipEventRecord(r.b, st));
-        std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(r);
-        return;
-    }
+    const int pi = mi_prof_begin(st, L, T, DUAL);
     fn<<<grid, NW*WAVE, lds, st>>>(L);
+    mi_prof_end(st, pi);
 }
 template <int TYPE, int T> static void launch_T(hipStream_t st, const mmvq_launch & L) {
     if (L.act.pre) { if (L.swiglu) launch_one<TYPE, T, 8, true, true >(st, L); else launch_one<TYPE, T, 8, false, true >(st, L); }
@@ -607,6 +478,11 @@ int mi_mmvq_max_tokens(int type, int k) {
 // ring of HBM scratch slots; entries are keyed by the ggml tensor that owns the activations (unique per graph_compute
 // epoch), so wq|wk and a differently-typed wv, or gate|up launched separately, share one image.
 static const int PRE_MIN_ELEMS = 8192;      // T*k above this: quantise once
+// K-quants with >= this many tokens go to the matrix-core kernel (kernels_mmq.hip); GGML_MI355X_MMQ_MIN_T overrides (0 = never)
+static int mmq_min_tokens() {
+    static const int v = [] { const char * e = getenv("GGML_MI355X_MMQ_MIN_T"); const int n = e ? atoi(e) : 2; return n <= 0 ? 1 << 30 : n; }();
+    return v;
+}
 void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_act_cache * cache, const void * key) {
     const int tmax = mi_mmvq_max_tokens(type, L0.k);
     MI_ASSERT(tmax >= 1);
@@ -618,7 +494,8 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
         L.act.pre = nullptr;
         for (int i = 0; i < L.n_mat; ++i) { L.m[i].out += (size_t) t0 * L.m[i].o_tok; if (L.m[i].res) L.m[i].res += (size_t) t0 * L.m[i].r_tok; }
         if (L.rope.pos) L.rope.pos += t0;
-        if (cache && cache->pool && (int64_t) T * L.k > PRE_MIN_ELEMS && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes) {
+        const bool mmq = cache && cache->pool && T >= mmq_min_tokens() && mi_mmq_supported(type, T, L.k) && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes;
+        if (cache && cache->pool && (mmq || (int64_t) T * L.k > PRE_MIN_ELEMS) && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes) {
             int hit = -1;
             if (key) for (int i = 0; i < MI_ACT_SLOTS; ++i) { const auto & e = cache->e[i]; if (e.key == key && e.epoch == cache->epoch && e.t0 == t0 && e.T == T && e.kq == kq && e.k == L.k) { hit = i; break; } }
             if (hit < 0) {
@@ -628,6 +505,7 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
             }
             L.act.pre = cache->pool + (size_t) hit * cache->slot_bytes;
         }
+        if (mmq) { mi_mmq_launch(st, type, T, L); continue; }
         switch (type) {
             case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, T, L); break;
             case GGML_TYPE_Q5_K: launch_type<GGML_TYPE_Q5_K>(st, T, L); break;
