@@ -124,6 +124,7 @@ static bool write_conflicts(const gctx & c, const void * p, size_t n, int at, in
     for (int j = at + 1; j < upto; ++j) {
         if (skip[j]) continue;
         const ggml_tensor * t = c.g->nodes[j];
+        if (is_view_op(t->op)) continue;                              // a view node touches no memory; whoever reads through it is checked by its src
         if (overlap(p, n, t->data, mi_nbytes(t))) return true;
         for (int s = 0; s < GGML_MAX_SRC; ++s) if (t->src[s] && overlap(p, n, t->src[s]->data, mi_nbytes(t->src[s]))) return true;
     }
@@ -326,13 +327,15 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
             std::vector<char> sk = skip; sk[m.node] = 1; for (int s : m.swallowed) sk[s] = 1;
             const int orig = m.swallowed.empty() ? m.node : std::max(m.node, *std::max_element(m.swallowed.begin(), m.swallowed.end()));
             const size_t nb = mi_nbytes(m.out);
-            if (write_conflicts(c, m.out->data, nb, i, orig, sk)) continue;           // leave it to run at its own position
-            if (overlap(m.out->data, nb, ap.src.X, (size_t) T * ap.src.xs * 4)) continue;
+            static const bool dbg = getenv("GGML_MI355X_DEBUG_GROUP") != nullptr;
+            if (write_conflicts(c, m.out->data, nb, i, orig, sk)) { if (dbg) MI_LOG("group at %s: member %s not hoisted (write conflict, epi %d, out %s)", t->name, m.mm->name, m.epi, m.out->name); continue; }   // leave it to run at its own position
+            if (overlap(m.out->data, nb, ap.src.X, (size_t) T * ap.src.xs * 4)) { if (dbg) MI_LOG("group at %s: member %s not hoisted (overlaps activations)", t->name, m.mm->name); continue; }
         }
         skip[m.node] = 1; for (int s : m.swallowed) skip[s] = 1;
         sel[keep++] = m;
     }
     if (keep == 0) return false;
+    { static const bool dbg = getenv("GGML_MI355X_DEBUG_GROUP") != nullptr; if (dbg) MI_LOG("group at %s: %d siblings, %d kept, T=%d", t->name, nm, keep, T); }
     mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = keep; L.swiglu = 0;
     for (int q = 0; q < keep; ++q) fill_mat(L.m[q], sel[q]);
     if (rope0) {

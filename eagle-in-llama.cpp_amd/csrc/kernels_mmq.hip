@@ -25,6 +25,8 @@
 #include "mmvq_device.h"
 #include <mutex>
 #include <unordered_map>
+#include <cstdio>
+#include <cstdlib>
 
 typedef float f32x4  __attribute__((ext_vector_type(4)));
 
@@ -283,6 +285,7 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
         if (lds > 48*1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
         int nb = 0;
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds));
+        if (getenv("GGML_MI355X_DEBUG_OCC")) fprintf(stderr, "[mi355x] occupancy fn=%p threads=%d lds=%zu -> %d blocks/CU\n", fn, threads, lds, nb);
         if (nb < 1) nb = 1;
         g_lds[fn] = lds; g_occ[fn] = nb;
     }
@@ -308,7 +311,7 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
     int total = 0;
     for (int i = 0; i < (L.swiglu ? 1 : L.n_mat); ++i) total += (L.m[i].rows + 15) / 16;
     // few row groups and a long k: 16 waves per group so that every wave still has <= ~3 super-blocks in sequence
-    const bool wide = total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu) <= 160*1024;
+    const bool wide = TYPE != GGML_TYPE_Q6_K && total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu) <= 160*1024;
     if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16>(st, T, L); else mmq_launch_one<TYPE, true, 8>(st, T, L); }
     else          { if (wide) mmq_launch_one<TYPE, false, 16>(st, T, L); else mmq_launch_one<TYPE, false, 8>(st, T, L); }
 }

@@ -1,0 +1,15 @@
+"""Prints the occupancy the plugin derives for its mat-vec kernels (GGML_MI355X_DEBUG_OCC=1) on a few shapes."""
+import sys, os
+os.environ["GGML_MI355X_DEBUG_OCC"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from conftest import load_package
+import numpy as np, qdata
+ea = load_package()
+gpu = ea.Backend.mi355x(0)
+rng = np.random.default_rng(0)
+for t in (12, 14):
+    for T in (1, 6, 8):
+        g = ea.Graph(gpu)
+        x = g.tensor(ea.F32, 4096, T); a = g.tensor(t, 4096, 8192); o = g.mul_mat(a, x)
+        g.alloc(); g.set(a, qdata.random_blocks(t, 8192, 4096, rng)); g.set(x, rng.standard_normal((T, 4096)).astype(np.float32))
+        g.compute(); print("type", t, "T", T, "ok", flush=True)
