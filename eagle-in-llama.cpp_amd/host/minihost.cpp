@@ -74,6 +74,23 @@ ggml_backend_buffer_t Backend::alloc_buffer(size_t size, int usage) {
     if (b) b->usage = (enum ggml_backend_buffer_usage) usage;
     return b;
 }
+void * Backend::host_alloc(size_t size) {
+    ggml_backend_buffer_type_t hb = dev->iface.get_host_buffer_type ? dev->iface.get_host_buffer_type(dev) : nullptr;
+    if (hb) {
+        ggml_backend_buffer_t b = hb->iface.alloc_buffer(hb, size);
+        if (b) { void * p = b->iface.get_base(b); host_blocks.push_back({ p, b }); return p; }
+    }
+    void * p = malloc(size ? size : 1);
+    host_blocks.push_back({ p, nullptr });
+    return p;
+}
+void Backend::host_free(void * p) {
+    for (size_t i = 0; i < host_blocks.size(); ++i) if (host_blocks[i].p == p) {
+        if (host_blocks[i].buf) free_buffer(host_blocks[i].buf); else free(p);
+        host_blocks.erase(host_blocks.begin() + i);
+        return;
+    }
+}
 void Backend::free_buffer(ggml_backend_buffer_t b) {
     // same sequence as ggml_backend_buffer_free (R/ggml/src/ggml-backend.cpp): backend hook, then the object
     if (!b) return;
@@ -220,6 +237,12 @@ bool Ctx::alloc() {
 void Ctx::reset_graph() { pool.clear(); nodes.clear(); reuse = true; }
 void Ctx::set(ggml_tensor * t, const void * data, size_t offset, size_t size) { t->buffer->iface.set_tensor(t->buffer, t, data, offset, size); }
 void Ctx::get(const ggml_tensor * t, void * data, size_t offset, size_t size) { t->buffer->iface.get_tensor(t->buffer, t, data, offset, size); }
+void Ctx::set_async(ggml_tensor * t, const void * data, size_t offset, size_t size) {
+    if (be->be->iface.set_tensor_async) be->be->iface.set_tensor_async(be->be, t, data, offset, size); else set(t, data, offset, size);
+}
+void Ctx::get_async(const ggml_tensor * t, void * data, size_t offset, size_t size) {
+    if (be->be->iface.get_tensor_async) be->be->iface.get_tensor_async(be->be, t, data, offset, size); else get(t, data, offset, size);
+}
 enum ggml_status Ctx::compute_async() {
     node_array.assign(nodes.begin(), nodes.end());
     memset(&graph, 0, sizeof(graph));

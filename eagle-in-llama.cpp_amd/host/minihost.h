@@ -42,6 +42,25 @@ struct Backend {
     bool supports_op(const ggml_tensor * t) const;
     ggml_backend_buffer_t alloc_buffer(size_t size, int usage);
     void free_buffer(ggml_backend_buffer_t b);
+    // page-locked host memory from the device's host buffer type (what llama.cpp uses for its input / output staging,
+    // R/src/llama.cpp:9210-9240); plain malloc when the backend has none (CPU).  Freed with host_free.
+    void * host_alloc(size_t size);
+    void   host_free(void * p);
+  private:
+    struct host_block { void * p; ggml_backend_buffer_t buf; };
+    std::vector<host_block> host_blocks;
+};
+
+// grow-only float array in page-locked memory: async device->host copies land here
+struct HostVec {
+    Backend * be = nullptr; float * p = nullptr; size_t n = 0, cap = 0;
+    ~HostVec() { if (p && be) be->host_free(p); }
+    void resize(size_t m) { if (m > cap) { if (p) { be->synchronize(); be->host_free(p); } cap = m + m/2 + 1024; p = (float *) be->host_alloc(cap * sizeof(float)); } n = m; }
+    void clear() { n = 0; }
+    float * data() { return p; } const float * data() const { return p; }
+    float * begin() { return p; } const float * begin() const { return p; }
+    size_t size() const { return n; }
+    float & operator[](size_t i) { return p[i]; } const float & operator[](size_t i) const { return p[i]; }
 };
 
 // Tensor arena + op list + device memory for one graph (or for a set of persistent tensors).
@@ -89,6 +108,10 @@ struct Ctx {
     void reset_graph();
     void set(ggml_tensor * t, const void * data, size_t offset, size_t size);
     void get(const ggml_tensor * t, void * data, size_t offset, size_t size);
+    // ordered on the backend's queue (ggml_backend_tensor_{set,get}_async); synchronous fall-back when the backend has no async copies.
+    // `data` must stay valid until the next synchronize().
+    void set_async(ggml_tensor * t, const void * data, size_t offset, size_t size);
+    void get_async(const ggml_tensor * t, void * data, size_t offset, size_t size);
     enum ggml_status compute();                  // graph_compute over `nodes` + synchronize
     enum ggml_status compute_async();
     enum ggml_status compute_range(int n0, int n1);   // nodes [n0, n1) only, asynchronous (tensor-parallel segments)

@@ -176,11 +176,11 @@ static void fill_identity(int type, uint8_t * dst, int64_t rows, int64_t k) {
     }
 }
 
-Model::~Model() {}
+Model::~Model() { if (stage_in && be) { be->synchronize(); be->host_free(stage_in); } }
 
 Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const SynthOptions & opt, const Model * target) {
     Model * m = new Model;
-    m->cfg = cfg; m->be = be;
+    m->cfg = cfg; m->be = be; m->logits.be = be; m->hidden.be = be;
     m->wctx.reset(new mh::Ctx(be)); m->wctx->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
     m->gctx.reset(new mh::Ctx(be)); m->gctx->usage = GGML_BACKEND_BUFFER_USAGE_COMPUTE;
     mh::Ctx & w = *m->wctx;
@@ -407,25 +407,50 @@ int Model::decode(const Batch & b, bool want_hidden) {
     if (!g.alloc()) return -3;
     const double t1 = now_us();
 
-    // ---- inputs (llama_set_inputs, R/src/llama-context.cpp:61-210)
-    static thread_local std::vector<float> embd, mask;
-    embd.resize((size_t) T * E);
-    for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; float * dst = embd.data() + (size_t) i * E; for (int j = 0; j < E; ++j) dst[j] = h2f(src[j]); }
-    g.set(inp_embd, embd.data(), 0, embd.size() * 4);
-    if (inp_hidd) g.set(inp_hidd, b.hidd.data(), 0, (size_t) T * E * 4);
-    g.set(inp_pos, b.pos.data(), 0, (size_t) T * 4);
-    g.set(inp_out, out_ids.data(), 0, (size_t) n_outputs * 4);
-    mask.assign((size_t) n_kv * Tpad, -INFINITY);
-    for (int j = 0; j < T; ++j) {
-        const uint64_t sbit = 1ull << b.seq_first[j]; const int32_t pos = b.pos[j];
-        float * row = mask.data() + (size_t) j * n_kv;
-        for (int i = 0; i < n_kv; ++i) if ((kv.cells[i].seqs & sbit) && kv.cells[i].pos <= pos) row[i] = 0.0f;
+    // ---- inputs (llama_set_inputs, R/src/llama-context.cpp:61-210).  The input tensors were created first, so they sit
+    // back to back in the compute buffer: their host image is assembled in page-locked memory and goes up as ONE
+    // asynchronous copy ordered before the graph (the reference issues one blocking ggml_backend_tensor_set per input).
+    ggml_tensor * inputs[5] = { inp_embd, inp_hidd, inp_pos, kq_mask, inp_out };
+    size_t span = 0; bool packed = true;
+    for (ggml_tensor * t : inputs) if (t) {
+        const ptrdiff_t off = (char *) t->data - (char *) inp_embd->data;
+        if (t->buffer != inp_embd->buffer || off < 0 || (size_t) off > ((size_t) 64 << 20)) { packed = false; break; }
+        span = std::max(span, (size_t) off + mh::nbytes(t));
     }
-    g.set(kq_mask, mask.data(), 0, mask.size() * 4);
+    if (packed && span > stage_cap) {
+        if (stage_in) { be->synchronize(); be->host_free(stage_in); }
+        stage_cap = span + span/2 + 4096; stage_in = (char *) be->host_alloc(stage_cap);
+    }
+    static thread_local std::vector<char> unpacked;
+    auto host_of = [&](ggml_tensor * t) -> char * {
+        if (packed) return stage_in + ((char *) t->data - (char *) inp_embd->data);
+        unpacked.resize(mh::nbytes(t)); return unpacked.data();
+    };
+    auto flush = [&](ggml_tensor * t, char * h) { if (!packed) g.set(t, h, 0, mh::nbytes(t)); };
+    {
+        float * embd = (float *) host_of(inp_embd);
+        for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; float * dst = embd + (size_t) i * E; for (int j = 0; j < E; ++j) dst[j] = h2f(src[j]); }
+        flush(inp_embd, (char *) embd);
+    }
+    if (inp_hidd) { char * h = host_of(inp_hidd); memcpy(h, b.hidd.data(), (size_t) T * E * 4); flush(inp_hidd, h); }
+    { char * h = host_of(inp_pos); memcpy(h, b.pos.data(), (size_t) T * 4); flush(inp_pos, h); }
+    { char * h = host_of(inp_out); memcpy(h, out_ids.data(), (size_t) n_outputs * 4); flush(inp_out, h); }
+    {
+        float * mask = (float *) host_of(kq_mask);
+        std::fill(mask, mask + (size_t) n_kv * Tpad, -INFINITY);
+        for (int j = 0; j < T; ++j) {
+            const uint64_t sbit = 1ull << b.seq_first[j]; const int32_t pos = b.pos[j];
+            float * row = mask + (size_t) j * n_kv;
+            for (int i = 0; i < n_kv; ++i) if ((kv.cells[i].seqs & sbit) && kv.cells[i].pos <= pos) row[i] = 0.0f;
+        }
+        flush(kq_mask, (char *) mask);
+    }
+    if (packed) g.set_async(inp_embd, stage_in, 0, span);
     const double t2 = now_us();
 
+    // ---- compute, then the outputs by asynchronous copies into page-locked memory, one wait for everything
     enum ggml_status st = GGML_STATUS_SUCCESS;
-    if (!tp) st = g.compute();
+    if (!tp) st = g.compute_async();
     else {
         int n0 = 0;
         for (auto & c : cuts) {
@@ -434,17 +459,17 @@ int Model::decode(const Batch & b, bool want_hidden) {
             n0 = c.node_end;
         }
         if (st == GGML_STATUS_SUCCESS) st = g.compute_range(n0, (int) g.nodes.size());
-        be->synchronize();
     }
-    const double t3 = now_us();
-    if (st != GGML_STATUS_SUCCESS) { return st == GGML_STATUS_ABORTED ? 2 : -4; }
-
-    // ---- outputs
-    if (head_here) {
+    const double t3a = now_us();
+    if (st == GGML_STATUS_SUCCESS && head_here) {
         logits.resize((size_t) n_outputs * cfg.n_vocab);
-        g.get(result_output, logits.data(), 0, logits.size() * 4);
-        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get(result_norm, hidden.data(), 0, hidden.size() * 4); }
+        g.get_async(result_output, logits.data(), 0, logits.size() * 4);
+        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(result_norm, hidden.data(), 0, hidden.size() * 4); }
     } else { logits.clear(); hidden.clear(); }
+    be->synchronize();
+    const double t3 = now_us();
+    g.t_issue_us += t3a - t2; g.t_wait_us += t3 - t3a;
+    if (st != GGML_STATUS_SUCCESS) { return st == GGML_STATUS_ABORTED ? 2 : -4; }
     kv.head += T;
     if (kv.head >= kv.size) kv.head = 0;
     const double t4 = now_us();

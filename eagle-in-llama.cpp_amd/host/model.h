@@ -82,8 +82,9 @@ struct Model {
     size_t weight_bytes = 0;          // bytes of all mat-mul weights resident on the device (for the roofline)
 
     // outputs of the last decode
-    std::vector<float> logits;        // [n_outputs][n_vocab]
-    std::vector<float> hidden;        // [n_outputs][n_embd]  (result_norm rows: the hidden-state channel)
+    mh::HostVec logits;               // [n_outputs][n_vocab]   page-locked: the device writes it with an async copy
+    mh::HostVec hidden;               // [n_outputs][n_embd]    (result_norm rows: the hidden-state channel)
+    char * stage_in = nullptr; size_t stage_cap = 0;   // page-locked image of the input tensors of one decode
     std::vector<int32_t> out_ids;     // batch index of each output row
     int n_outputs = 0;
     // timing / stats
