@@ -129,25 +129,27 @@ template <> __device__ __forceinline__ void mq_process<GGML_TYPE_Q6_K>(const mq_
     const bool tv = tok_a < A.T && cls_a == lh;
     const int8_t * arow = A.q + tok_a*A.ldq + sb*256 + 16*lh;
     int isum[4] = {0, 0, 0, 0};
+    const int cls = g >> 1;
 #pragma unroll
-    for (int nn = 0; nn < 2; ++nn)
+    for (int nn = 0; nn < 2; ++nn) {
+        const i32x4 hq = f.qh[nn] >> (2*qb);                               // bits 2q.. for q = qb (nib 0) at bit 0, for q = qb + 2 (nib 1) at bit 4
 #pragma unroll
         for (int nib = 0; nib < 2; ++nib) {
-            const i32x4 nb = nib ? ((f.ql[nn] >> 4) & 0x0F0F0F0F) : (f.ql[nn] & 0x0F0F0F0F);
-            const i32x4 hb = qb ? (f.qh[nn] >> 2) : f.qh[nn];               // bits 2q.. with q = qb + 2nib
-            const i32x4 b = nb | (((hb >> (4*nib)) & 0x03030303) << 4);
-            const uint32_t sw = (uint32_t) f.sc[2*nn + nib];                // scales[8nn + 4nib + 0..3] = sub-blocks 8nn + 2(2nib + p) + lh, p = 0, 1
+            const i32x4 b = nib ? (((f.ql[nn] >> 4) & 0x0F0F0F0F) | (hq & 0x30303030)) : ((f.ql[nn] & 0x0F0F0F0F) | ((hq << 4) & 0x30303030));
+            // scales[8nn + 4nib + 2p + lh]: the class of a C lane is lh -> shift once, then bytes 0 / 2 are passes p = 0 / 1
+            const uint32_t sw = (uint32_t) f.sc[2*nn + nib] >> (8*cls);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int q = p + 2*nib;
                 const i32x4 a = (tv && qb == p) ? *(const i32x4 *)(arow + 128*nn + 32*q) : (i32x4)(0);
                 const i32x4 c = mfma_i8(a, b);
-                // C lane g: class g>>1 = lh of the sub-block -> scale of sub-block 8nn + 2q + (g>>1)
-                const int sc = (g >> 1) ? sbyte_of(sw, 2*p + 1) : sbyte_of(sw, 2*p);
+                const int sc = sbyte_of(sw, 2*p);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) isum[r] += __mul24(sc, c[r]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);                                  // keep the two halves apart: bounds the live A / B operands
+    }
     // -32 offset: 32 * sum_j scale_j * bsum16_j (class 0 = l parts, class 1 = h parts of the split sums)
     const bool mv = kq == 0 && tok_a < A.T;
     const i32x4 am = mv ? *(const i32x4 *)(A.rec + (tok_a*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
@@ -168,7 +170,9 @@ static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual) {
     return (size_t) T*(k + 16) + (((size_t) T*nsb*4 + 15) & ~(size_t) 15) + (size_t) T*nsb*32 + (size_t) NW*64*16*(dual ? 2 : 1);
 }
 
-template <int TYPE, bool DUAL, int NW>
+// PF: double-buffer the weight fragments (the loads of unit u+1 fly while unit u is computed); without it a wave keeps one
+// fragment set and relies on the other waves of its SIMD to cover the load latency (Q6_K: the register budget for 4 waves/SIMD)
+template <int TYPE, bool DUAL, int NW, bool PF>
 __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int k = L.k, nsb = k/256, ldq = k + 16;
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
     };
     auto unit_ptr = [&](int u) -> const char * { return DUAL ? rp[u & 1] + (size_t)(wave + (u >> 1)*NW) * BLK : rp[0] + (size_t)(wave + u*NW) * BLK; };
 
-    mq_frag<TYPE> fa, fb;
+    mq_frag<TYPE> fa, fb;          // fb unused without PF
     int grp = blockIdx.x, mi = 0, row0 = 0;
     if (grp < total) { set_rows(grp, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq); }      // in flight across the prologue
     {   // activation image (HBM scratch, written by k_quant_act) -> LDS; token rows padded by 16 bytes against bank conflicts
@@ -216,12 +220,20 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
         for (int m = 0; m < NM; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
-        for (int u = 0; u < nu; u += 2) {
-            if (u + 1 < nu) fb.load(unit_ptr(u + 1), kq);
-            mq_process<TYPE>(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[DUAL ? (u & 1) : 0]);
-            if (u + 1 >= nu) break;
-            if (u + 2 < nu) fa.load(unit_ptr(u + 2), kq);
-            mq_process<TYPE>(fb, A, DUAL ? wave + ((u + 1) >> 1)*NW : wave + (u + 1)*NW, lane, acc[DUAL ? ((u + 1) & 1) : 0]);
+        if (PF) {
+            for (int u = 0; u < nu; u += 2) {
+                if (u + 1 < nu) fb.load(unit_ptr(u + 1), kq);
+                mq_process<TYPE>(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[0]);                 // DUAL: even units = gate
+                if (u + 1 >= nu) break;
+                if (u + 2 < nu) fa.load(unit_ptr(u + 2), kq);
+                mq_process<TYPE>(fb, A, DUAL ? wave + ((u + 1) >> 1)*NW : wave + (u + 1)*NW, lane, acc[NM - 1]);   // DUAL: odd units = up
+            }
+        } else {
+            for (int u = 0; u < nu; u += NM) {
+                mq_process<TYPE>(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[0]);
+                if (DUAL) { fa.load(unit_ptr(u + 1), kq); mq_process<TYPE>(fa, A, wave + (u >> 1)*NW, lane, acc[NM - 1]); }
+                if (u + NM < nu) fa.load(unit_ptr(u + NM), kq);
+            }
         }
         // next group's first loads go out before this group's reduction / epilogue
         const int cmi = mi, crow0 = row0, gn = grp + gridDim.x;
@@ -292,14 +304,14 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
     return g_occ[fn];
 }
 
-template <int TYPE, bool DUAL, int NW> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
+template <int TYPE, bool DUAL, int NW, bool PF> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
     const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL);
     MI_ASSERT(lds <= 160*1024 && L.act.pre);
     int total = 0;
     if (DUAL) total = (L.m[0].rows + 15) / 16;
     else for (int i = 0; i < L.n_mat; ++i) total += (L.m[i].rows + 15) / 16;
     if (total < 1) return;
-    auto fn = k_mmq<TYPE, DUAL, NW>;
+    auto fn = k_mmq<TYPE, DUAL, NW, PF>;
     int per_cu = blocks_per_cu((const void *) fn, NW*WAVE, lds);
     if (per_cu > 4) per_cu = 4;
     const int grid = total < 256*per_cu ? total : 256*per_cu;
@@ -310,10 +322,11 @@ template <int TYPE, bool DUAL, int NW> static void mmq_launch_one(hipStream_t st
 template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmvq_launch & L) {
     int total = 0;
     for (int i = 0; i < (L.swiglu ? 1 : L.n_mat); ++i) total += (L.m[i].rows + 15) / 16;
+    constexpr bool PF = TYPE != GGML_TYPE_Q6_K;
     // few row groups and a long k: 16 waves per group so that every wave still has <= ~3 super-blocks in sequence
-    const bool wide = TYPE != GGML_TYPE_Q6_K && total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu) <= 160*1024;
-    if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16>(st, T, L); else mmq_launch_one<TYPE, true, 8>(st, T, L); }
-    else          { if (wide) mmq_launch_one<TYPE, false, 16>(st, T, L); else mmq_launch_one<TYPE, false, 8>(st, T, L); }
+    const bool wide = total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu) <= 160*1024;
+    if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false>(st, T, L); else mmq_launch_one<TYPE, true, 8, PF>(st, T, L); }
+    else          { if (wide) mmq_launch_one<TYPE, false, 16, PF>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF>(st, T, L); }
 }
 
 bool mi_mmq_supported(int type, int T, int k) {
