@@ -55,6 +55,16 @@ def plugin_profile(ea):
     return lib
 
 
+def pmc_traffic():
+    """HBM bytes per mat-vec launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same command
+    (profiles/r01_pmc_traffic.json, written by scripts/pmc_summary.py; counters cannot be read from inside the run)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(ea, cfg, ftype):
     """The reference's own ggml CPU backend (oracle/_ref, built from /root/reference) running the SAME driver on a
     bounded sample of the same workload.  Falls back to nothing (null) when oracle/_ref is absent."""
@@ -123,17 +133,20 @@ def main():
     sess.rounds(args.steps, n_draft=N_DRAFT)
     out = (C.c_double * 4)()
     n_launch = prof.ggml_backend_mi355x_profile_end(out)
-    kern_ms, alg_bytes = out[0], out[1]
+    raw_ms, alg_bytes, pair_ms = out[0], out[1], out[2]
     sess.close()
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_mmvq (quantised weight x f32 activations, 1..8 tokens)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+    # an event pair with nothing in between still measures `pair_ms` (queue markers): the kernel time is net of it
+    kern_ms = max(raw_ms - pair_ms * n_launch, 1e-9)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if n_launch > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "quantised mat-vec family: k_mmq (int8 MFMA, 2..8 tokens) + k_mmvq (dp4a, 1 token)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
                 "launches": n_launch, "avg_launch_us": round(kern_ms * 1e3 / max(1, n_launch), 2),
+                "avg_launch_us_raw_event_pair": round(raw_ms * 1e3 / max(1, n_launch), 2), "empty_event_pair_us": round(pair_ms * 1e3, 2),
                 "algorithmic_bytes_per_launch": round(alg_bytes / max(1, n_launch))}
 
     res = {"metric": "accepted tokens/sec + accept-rate, Vicuna-7B Q4_K_M + EAGLE, 1/8 GPU", "value": round(value, 2), "unit": "tokens/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 (dp4a) -> f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 -> int32 (MFMA / dp4a) -> f32", "data": "synthetic",
            "config": {"workload": f"{args.config} {args.ftype} target + EAGLE head, chain/tree depth {N_DRAFT} (verify batch {N_DRAFT+1}), "
                                   f"{PROMPT_LEN}-token synthetic prompt, greedy", "n_draft": N_DRAFT, "accept_p_synthetic": args.accept_p},
            "accept_rate": round(st["n_accept"] / max(1.0, st["n_drafted"]), 4), "tokens_per_round": round(st["n_predict"] / args.steps, 3),

@@ -109,7 +109,7 @@ def main_tp(args, rank, world, local):
     if rank == 0:
         res = {"metric": "accepted tokens/sec + accept-rate, Vicuna-7B Q4_K_M + EAGLE, 1/8 GPU", "value": round(n_tok / dt, 2), "unit": "tokens/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 (dp4a) -> f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 -> int32 (MFMA / dp4a) -> f32", "data": "synthetic",
                "config": {"workload": f"{args.config} {args.ftype} target row-split TP={world} (2 RCCL all-reduces/layer) + EAGLE head on rank 0, depth {N_DRAFT}, "
                                       f"{PROMPT_LEN}-token synthetic prompt, greedy", "n_draft": N_DRAFT, "accept_p_synthetic": args.accept_p},
                "accept_rate": round(st[2] / max(1.0, st[1]), 4), "tokens_per_round": round(n_tok / args.steps, 3),

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "kernels.h"
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 #include <unordered_set>
@@ -383,12 +384,13 @@ static void ensure_lds_attr(const void * fn, size_t bytes) {
 // ---- optional HIP-event profile of every mat-vec launch (bench.py roofline; off by default, zero cost when off)
 struct prof_rec { hipEvent_t a, b; double bytes; };
 static bool g_prof_on = false;
-static std::vector<prof_rec> g_prof;
+static std::vector<prof_rec> g_prof, g_prof_cal;     // g_prof_cal: empty event pairs, the cost of the bracket itself
 static std::mutex g_prof_mu;
 extern "C" __attribute__((visibility("default"))) void ggml_backend_mi355x_profile_begin(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto & r : g_prof) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
-    g_prof.clear(); g_prof_on = true;
+    for (auto & r : g_prof_cal) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
+    g_prof.clear(); g_prof_cal.clear(); g_prof_on = true;
 }
 // out[0] = total kernel milliseconds, out[1] = total algorithmic bytes; returns the number of launches
 extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_profile_end(double * out) {
@@ -398,7 +400,13 @@ extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_profil
     for (auto & r : g_prof) { float t = 0; if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms += t; bytes += r.bytes; } (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     const int n = (int) g_prof.size();
     g_prof.clear();
-    if (out) { out[0] = ms; out[1] = bytes; }
+    // out[2]: milliseconds an EMPTY event pair measures on the same stream (median of the calibration pairs): what the
+    // bracket adds to every launch; bench.py reports kernel time net of it
+    std::vector<float> cal;
+    for (auto & r : g_prof_cal) { float t = 0; if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) cal.push_back(t); (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
+    g_prof_cal.clear();
+    std::sort(cal.begin(), cal.end());
+    if (out) { out[0] = ms; out[1] = bytes; out[2] = cal.empty() ? 0.0 : cal[cal.size()/2]; out[3] = (double) cal.size(); }
     return n;
 }
 // algorithmic bytes of one launch: weights once + fp32 activations once + outputs once
@@ -416,6 +424,10 @@ static inline size_t lds_total(bool ktype, int T, int k, int NW) { return act_ld
 // profile hooks shared with kernels_mmq.hip: returns a record index (or -1 when profiling is off)
 int mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual) {
     if (!g_prof_on) return -1;
+    {   // every 64th launch: one empty pair right before, same stream, same queue state
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof.size() % 64 == 0) { prof_rec c; HIP_CHECK(hipEventCreate(&c.a)); HIP_CHECK(hipEventCreate(&c.b)); c.bytes = 0; HIP_CHECK(hipEventRecord(c.a, st)); HIP_CHECK(hipEventRecord(c.b, st)); g_prof_cal.push_back(c); }
+    }
     prof_rec r; HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b)); r.bytes = launch_bytes(L, T, dual);
     HIP_CHECK(hipEventRecord(r.a, st));
     std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(r);
