@@ -73,9 +73,10 @@ struct mq_act { const int8_t * q; int ldq; const float * d; const char * rec; in
 // tokens against the k-slots of one sub-block, M rows 8..15 the same tokens against another sub-block, the activations
 // being zero in the k-slots of the other class.  C lane (n, g = lane>>4), reg r: M row 4g + r, i.e. class g>>1, token
 // 4*(g&1) + r: acc[r] is this lane's share (its class) of out[row n][token 4*(g&1) + r]; classes are added in the reduction.
-template <int TYPE> __device__ __forceinline__ void mq_process(const mq_frag<TYPE> & f, const mq_act & A, int sb, int lane, float (&acc)[4]);
+// TG groups of 8 tokens per pass: the B operands (unpacked quants) are built once and multiplied with TG activation operands.
+template <int TYPE, int TG> struct mq_proc;
 
-template <int TYPE> __device__ __forceinline__ void mq_process_q45(const mq_frag<TYPE> & f, const mq_act & A, int sb, int lane, float (&acc)[4]) {
+template <int TYPE, int TG> __device__ __forceinline__ void mq_process_q45(const mq_frag<TYPE> & f, const mq_act & A, int sb, int lane, float (&acc)[TG][4]) {
     const int i = lane & 15, kq = lane >> 4, g = kq;
     const uint32_t u0 = f.hdr.y, u1 = f.hdr.z, u2 = f.hdr.w;             // get_scale_min_k4 for all eight sub-blocks (ggml-quants.c:631-638)
     const uint32_t s_lo = u0 & 0x3f3f3f3fu, s_hi = (u2 & 0x0f0f0f0fu) | ((u0 >> 2) & 0x30303030u);
@@ -84,10 +85,14 @@ template <int TYPE> __device__ __forceinline__ void mq_process_q45(const mq_frag
     // B: lanes kq<2 hold group gA = {0,1}, lanes kq>=2 group gA + 2; k-slots 16*(kq&1).. of the 32-element sub-block.
     // A: M row i<8 = token i, active in k-slots kq<2 (class 0: sub-blocks 2gA, 2gA+1); M row i>=8 = token i-8, active in kq>=2 (class 1)
     const int  tok_a = i & 7, cls_a = i >> 3;
-    const bool av = tok_a < A.T && cls_a == (kq >> 1);
+    const bool cv = cls_a == (kq >> 1);
     const int8_t * arow = A.q + tok_a*A.ldq + sb*256 + 128*cls_a + 16*(kq & 1);
     const uint32_t sw = (g >> 1) ? s_hi : s_lo;                           // scales of this lane's class: sub-blocks 4*cls + 0..3
-    int isum[4] = {0, 0, 0, 0};
+    int isum[TG][4];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) isum[t][r] = 0;
 #pragma unroll
     for (int ga = 0; ga < 2; ++ga) {
         i32x4 blo = f.qs[ga] & 0x0F0F0F0F, bhi = (f.qs[ga] >> 4) & 0x0F0F0F0F;
@@ -95,40 +100,51 @@ template <int TYPE> __device__ __forceinline__ void mq_process_q45(const mq_frag
             const i32x4 hb = (kq >> 1) ? (f.qh >> 4) : f.qh;
             blo |= ((hb >> (2*ga)) & 0x01010101) << 4; bhi |= ((hb >> (2*ga + 1)) & 0x01010101) << 4;
         }
-        const i32x4 alo = av ? *(const i32x4 *)(arow + 64*ga) : (i32x4)(0);
-        const i32x4 ahi = av ? *(const i32x4 *)(arow + 64*ga + 32) : (i32x4)(0);
-        const i32x4 c0 = mfma_i8(alo, blo);
-        const i32x4 c1 = mfma_i8(ahi, bhi);
         const int s0 = byte_of(sw, 2*ga), s1 = byte_of(sw, 2*ga + 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) isum[r] += __mul24(s0, c0[r]) + __mul24(s1, c1[r]);
+        for (int t = 0; t < TG; ++t) {
+            const bool av = cv && tok_a + 8*t < A.T;
+            const i32x4 alo = av ? *(const i32x4 *)(arow + 8*t*A.ldq + 64*ga) : (i32x4)(0);
+            const i32x4 ahi = av ? *(const i32x4 *)(arow + 8*t*A.ldq + 64*ga + 32) : (i32x4)(0);
+            const i32x4 c0 = mfma_i8(alo, blo);
+            const i32x4 c1 = mfma_i8(ahi, bhi);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) isum[t][r] += __mul24(s0, c0[r]) + __mul24(s1, c1[r]);
+        }
     }
     // mins: sum_j m_j * bsum32_j with the sums split as 128*h + l: class 0 = l parts, class 1 = h parts, both in k-slots kq = 0
-    const bool mv = kq == 0 && tok_a < A.T;
-    const i32x4 am = mv ? *(const i32x4 *)(A.rec + (tok_a*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
     i32x4 bm = {0, 0, 0, 0};
     if (kq == 0) { bm.x = (int) m_lo; bm.y = (int) m_hi; }
-    const i32x4 cm = mfma_i8(am, bm);
     const float mscale = (g >> 1) ? 128.f : 1.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int tok = 4*(g & 1) + r;
-        const float dy = tok < A.T ? A.d[tok*A.nsb + sb] : 0.f;
-        acc[r] += (dw*dy)*(float) isum[r] - ((mw*dy)*mscale)*(float) cm[r];
+    for (int t = 0; t < TG; ++t) {
+        const bool mv = kq == 0 && tok_a + 8*t < A.T;
+        const i32x4 am = mv ? *(const i32x4 *)(A.rec + ((tok_a + 8*t)*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
+        const i32x4 cm = mfma_i8(am, bm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tok = 8*t + 4*(g & 1) + r;
+            const float dy = tok < A.T ? A.d[tok*A.nsb + sb] : 0.f;
+            acc[t][r] += (dw*dy)*(float) isum[t][r] - ((mw*dy)*mscale)*(float) cm[r];
+        }
     }
 }
-template <> __device__ __forceinline__ void mq_process<GGML_TYPE_Q4_K>(const mq_frag<GGML_TYPE_Q4_K> & f, const mq_act & A, int sb, int lane, float (&acc)[4]) { mq_process_q45<GGML_TYPE_Q4_K>(f, A, sb, lane, acc); }
-template <> __device__ __forceinline__ void mq_process<GGML_TYPE_Q5_K>(const mq_frag<GGML_TYPE_Q5_K> & f, const mq_act & A, int sb, int lane, float (&acc)[4]) { mq_process_q45<GGML_TYPE_Q5_K>(f, A, sb, lane, acc); }
+template <int TG> struct mq_proc<GGML_TYPE_Q4_K, TG> { static __device__ __forceinline__ void run(const mq_frag<GGML_TYPE_Q4_K> & f, const mq_act & A, int sb, int lane, float (&acc)[TG][4]) { mq_process_q45<GGML_TYPE_Q4_K, TG>(f, A, sb, lane, acc); } };
+template <int TG> struct mq_proc<GGML_TYPE_Q5_K, TG> { static __device__ __forceinline__ void run(const mq_frag<GGML_TYPE_Q5_K> & f, const mq_act & A, int sb, int lane, float (&acc)[TG][4]) { mq_process_q45<GGML_TYPE_Q5_K, TG>(f, A, sb, lane, acc); } };
 
-template <> __device__ __forceinline__ void mq_process<GGML_TYPE_Q6_K>(const mq_frag<GGML_TYPE_Q6_K> & f, const mq_act & A, int sb, int lane, float (&acc)[4]) {
+template <int TG> struct mq_proc<GGML_TYPE_Q6_K, TG> { static __device__ __forceinline__ void run(const mq_frag<GGML_TYPE_Q6_K> & f, const mq_act & A, int sb, int lane, float (&acc)[TG][4]) {
     const int i = lane & 15, kq = lane >> 4, g = kq, qb = kq >> 1, lh = kq & 1;
     // element 128nn + 32q + l (l = 16lh + byte): ql[64nn + 32(q&1) + l] nibble q>>1, qh[32nn + l] bits 2q, 2q+1; 16-element
     // sub-block s = 8nn + 2q + lh.  B operand (nn, nib): lane kq holds q = qb + 2nib.  Two MFMAs use it: pass p activates
     // the k-slots of the lanes with qb == p; in a pass, class (M rows 0..7 | 8..15) = lh.
     const int  tok_a = i & 7, cls_a = i >> 3;
-    const bool tv = tok_a < A.T && cls_a == lh;
+    const bool cv = cls_a == lh;
     const int8_t * arow = A.q + tok_a*A.ldq + sb*256 + 16*lh;
-    int isum[4] = {0, 0, 0, 0};
+    int isum[TG][4];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) isum[t][r] = 0;
     const int cls = g >> 1;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
@@ -141,38 +157,44 @@ template <> __device__ __forceinline__ void mq_process<GGML_TYPE_Q6_K>(const mq_
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int q = p + 2*nib;
-                const i32x4 a = (tv && qb == p) ? *(const i32x4 *)(arow + 128*nn + 32*q) : (i32x4)(0);
-                const i32x4 c = mfma_i8(a, b);
                 const int sc = sbyte_of(sw, 2*p);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) isum[r] += __mul24(sc, c[r]);
+                for (int t = 0; t < TG; ++t) {
+                    const i32x4 a = (cv && qb == p && tok_a + 8*t < A.T) ? *(const i32x4 *)(arow + 8*t*A.ldq + 128*nn + 32*q) : (i32x4)(0);
+                    const i32x4 c = mfma_i8(a, b);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) isum[t][r] += __mul24(sc, c[r]);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);                                  // keep the two halves apart: bounds the live A / B operands
     }
     // -32 offset: 32 * sum_j scale_j * bsum16_j (class 0 = l parts, class 1 = h parts of the split sums)
-    const bool mv = kq == 0 && tok_a < A.T;
-    const i32x4 am = mv ? *(const i32x4 *)(A.rec + (tok_a*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
     const i32x4 bm = kq == 0 ? f.sc : (i32x4)(0);
-    const i32x4 cm = mfma_i8(am, bm);
     const float dw = h2f((uint16_t) f.dh);
     const int mscale = (g >> 1) ? 128*32 : 32;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int tok = 4*(g & 1) + r;
-        const float dy = tok < A.T ? A.d[tok*A.nsb + sb] : 0.f;
-        acc[r] += (dw*dy)*(float)(isum[r] - mscale*cm[r]);
+    for (int t = 0; t < TG; ++t) {
+        const bool mv = kq == 0 && tok_a + 8*t < A.T;
+        const i32x4 am = mv ? *(const i32x4 *)(A.rec + ((tok_a + 8*t)*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
+        const i32x4 cm = mfma_i8(am, bm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tok = 8*t + 4*(g & 1) + r;
+            const float dy = tok < A.T ? A.d[tok*A.nsb + sb] : 0.f;
+            acc[t][r] += (dw*dy)*(float)(isum[t][r] - mscale*cm[r]);
+        }
     }
-}
+} };
 
 static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual) {
     const size_t nsb = k/256;
-    return (size_t) T*(k + 16) + (((size_t) T*nsb*4 + 15) & ~(size_t) 15) + (size_t) T*nsb*32 + (size_t) NW*64*16*(dual ? 2 : 1);
+    return (size_t) T*(k + 16) + (((size_t) T*nsb*4 + 15) & ~(size_t) 15) + (size_t) T*nsb*32 + (size_t) NW*64*16*(dual ? 2 : 1);      // the reduction tiles are re-used per token group
 }
 
 // PF: double-buffer the weight fragments (the loads of unit u+1 fly while unit u is computed); without it a wave keeps one
 // fragment set and relies on the other waves of its SIMD to cover the load latency (Q6_K: the register budget for 4 waves/SIMD)
-template <int TYPE, bool DUAL, int NW, bool PF>
+template <int TYPE, bool DUAL, int NW, bool PF, int TG>
 __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int k = L.k, nsb = k/256, ldq = k + 16;
@@ -215,40 +237,45 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
     const mq_act A = { lq, ldq, ldy, lrec, nsb, T };
 
     while (grp < total) {
-        float acc[NM][4];
+        float acc[NM][TG][4];
 #pragma unroll
         for (int m = 0; m < NM; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
+            for (int t = 0; t < TG; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][t][r] = 0.f;
         if (PF) {
             for (int u = 0; u < nu; u += 2) {
                 if (u + 1 < nu) fb.load(unit_ptr(u + 1), kq);
-                mq_process<TYPE>(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[0]);                 // DUAL: even units = gate
+                mq_proc<TYPE, TG>::run(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[0]);                 // DUAL: even units = gate
                 if (u + 1 >= nu) break;
                 if (u + 2 < nu) fa.load(unit_ptr(u + 2), kq);
-                mq_process<TYPE>(fb, A, DUAL ? wave + ((u + 1) >> 1)*NW : wave + (u + 1)*NW, lane, acc[NM - 1]);   // DUAL: odd units = up
+                mq_proc<TYPE, TG>::run(fb, A, DUAL ? wave + ((u + 1) >> 1)*NW : wave + (u + 1)*NW, lane, acc[NM - 1]);   // DUAL: odd units = up
             }
         } else {
             for (int u = 0; u < nu; u += NM) {
-                mq_process<TYPE>(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[0]);
-                if (DUAL) { fa.load(unit_ptr(u + 1), kq); mq_process<TYPE>(fa, A, wave + (u >> 1)*NW, lane, acc[NM - 1]); }
+                mq_proc<TYPE, TG>::run(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[0]);
+                if (DUAL) { fa.load(unit_ptr(u + 1), kq); mq_proc<TYPE, TG>::run(fa, A, wave + (u >> 1)*NW, lane, acc[NM - 1]); }
                 if (u + NM < nu) fa.load(unit_ptr(u + NM), kq);
             }
         }
         // next group's first loads go out before this group's reduction / epilogue
         const int cmi = mi, crow0 = row0, gn = grp + gridDim.x;
         if (gn < total) { set_rows(gn, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq); }
-        // ---- split-K reduction in a fixed order (wave 0 adds the partial tiles of waves 0..NW-1)
-        __syncthreads();                                                   // wave 0 is done with the previous group's tiles
+        // ---- split-K reduction in a fixed order (wave 0 adds the partial tiles of waves 0..NW-1), one token group at a time
 #pragma unroll
-        for (int m = 0; m < NM; ++m) { const f32x4 v = { acc[m][0], acc[m][1], acc[m][2], acc[m][3] }; red[(m*NW + wave)*WAVE + lane] = v; }
+        for (int tgi = 0; tgi < TG; ++tgi) {
+        if (tgi*8 >= T) break;
+        __syncthreads();                                                   // wave 0 is done with the previous tiles
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { const f32x4 v = { acc[m][tgi][0], acc[m][tgi][1], acc[m][tgi][2], acc[m][tgi][3] }; red[(m*NW + wave)*WAVE + lane] = v; }
         __syncthreads();
         if (wave == 0) {
             f32x4 v[NM];                                                    // both classes (lanes l, l^32) of all waves: every lane ends with the full sums
 #pragma unroll
             for (int m = 0; m < NM; ++m) { v[m] = red[(m*NW)*WAVE + lane] + red[(m*NW)*WAVE + (lane ^ 32)]; for (int w = 1; w < NW; ++w) v[m] += red[(m*NW + w)*WAVE + lane] + red[(m*NW + w)*WAVE + (lane ^ 32)]; }
             const mmvq_mat & M = L.m[cmi];
-            const int row = crow0 + (lane & 15), tg = kq & 1;
+            const int row = crow0 + (lane & 15), tg = 2*tgi + (kq & 1);
             const bool in = row < M.rows && kq < 2;
             if (DUAL) {
 #pragma unroll
@@ -281,6 +308,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
                 }
             }
         }
+        }   // token groups
         grp = gn;
     }
 }
@@ -304,14 +332,14 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
     return g_occ[fn];
 }
 
-template <int TYPE, bool DUAL, int NW, bool PF> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
+template <int TYPE, bool DUAL, int NW, bool PF, int TG> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
     const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL);
     MI_ASSERT(lds <= 160*1024 && L.act.pre);
     int total = 0;
     if (DUAL) total = (L.m[0].rows + 15) / 16;
     else for (int i = 0; i < L.n_mat; ++i) total += (L.m[i].rows + 15) / 16;
     if (total < 1) return;
-    auto fn = k_mmq<TYPE, DUAL, NW, PF>;
+    auto fn = k_mmq<TYPE, DUAL, NW, PF, TG>;
     int per_cu = blocks_per_cu((const void *) fn, NW*WAVE, lds);
     if (per_cu > 4) per_cu = 4;
     const int grid = total < 256*per_cu ? total : 256*per_cu;
@@ -323,20 +351,30 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
     int total = 0;
     for (int i = 0; i < (L.swiglu ? 1 : L.n_mat); ++i) total += (L.m[i].rows + 15) / 16;
     constexpr bool PF = TYPE != GGML_TYPE_Q6_K;
+    if (T > 8) {      // several groups of 8 tokens per pass (prompt / large verification batches): weights and their unpacking are shared
+        const int tg = (T + 7) / 8;
+        // register budget: 3 groups (24 tokens) per pass, 2 for the dual gate|up kernel
+        MI_ASSERT(tg <= (L.swiglu ? 2 : 3));
+        if (L.swiglu) mmq_launch_one<TYPE, true, 8, PF, 2>(st, T, L);
+        else          { if (tg == 2) mmq_launch_one<TYPE, false, 8, PF, 2>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF, 3>(st, T, L); }
+        return;
+    }
     // few row groups and a long k: 16 waves per group so that every wave still has <= ~3 super-blocks in sequence
     const bool wide = total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu) <= 160*1024;
-    if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false>(st, T, L); else mmq_launch_one<TYPE, true, 8, PF>(st, T, L); }
-    else          { if (wide) mmq_launch_one<TYPE, false, 16, PF>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF>(st, T, L); }
+    if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false, 1>(st, T, L); else mmq_launch_one<TYPE, true, 8, PF, 1>(st, T, L); }
+    else          { if (wide) mmq_launch_one<TYPE, false, 16, PF, 1>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF, 1>(st, T, L); }
 }
 
-bool mi_mmq_supported(int type, int T, int k) {
+bool mi_mmq_supported(int type, int T, int k, bool swiglu) {
     if (!(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K)) return false;
-    if (T < 1 || T > 8 || k % 256) return false;
-    return mmq_lds_bytes(T, k, 8, true) <= 156*1024;
+    if (T < 1 || T > (swiglu ? 16 : 24) || k % 256) return false;
+    return mmq_lds_bytes(T, k, 8, true) <= 158*1024;
 }
-int mi_mmq_max_tokens(int type, int k) {
-    int t = 8;
-    while (t > 0 && !mi_mmq_supported(type, t, k)) --t;
+// most tokens one pass can take: a multiple of 8 (whole token groups) once above 8
+int mi_mmq_max_tokens(int type, int k, bool swiglu) {
+    for (int t = 24; t >= 8; t -= 8) if (mi_mmq_supported(type, t, k, swiglu)) return t;
+    int t = 7;
+    while (t > 0 && !mi_mmq_supported(type, t, k, swiglu)) --t;
     return t;
 }
 void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L) {

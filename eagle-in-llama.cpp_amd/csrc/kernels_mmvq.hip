@@ -331,31 +331,39 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
 
 // Quantise-once: the same prologue as a stand-alone kernel writing the LDS image to HBM scratch; used when the
 // image is big (T*k) so that 512 blocks do not each redo it.  Blocks share the units round-robin.
+// The image holds Ttot tokens; this launch quantises tokens t0 .. t0+T-1 of it (a.X already points at token t0).
 template <bool KQ, int T, int NW>
-__global__ void __launch_bounds__(NW*WAVE) k_quant_act(const act_src a, int k, char * out) {
+__global__ void __launch_bounds__(NW*WAVE) k_quant_act(const act_src a, int k, char * out, int Ttot, int t0) {
     __shared__ double red[NW*T];
     __shared__ float  sc[T];
     if (a.norm) row_scales<T, NW>(a, k, sc, red);
-    int8_t * q = (int8_t *) out;
-    float  * d = (float *)(out + T*k);
-    short  * bs = (short *)((char *) d + T*(KQ ? k/256 : k/32)*4);
+    const int nblk = KQ ? k/256 : k/32;
+    int8_t * q = (int8_t *) out + (size_t) t0*k;
+    float  * d = (float *)(out + (size_t) Ttot*k) + (size_t) t0*nblk;
+    short  * bs = (short *)(out + (size_t) Ttot*k + (size_t) Ttot*nblk*4) + (size_t) t0*(k/16);
     const int wave = threadIdx.x / WAVE;
-    if (KQ) quant_q8K_to_lds<T, NW>(a, sc, k, q, d, bs, blockIdx.x*NW + wave, gridDim.x*NW, out + act_img_bytes(true, T, k));
-    else    quant_q80_to_lds<T, NW>(a, sc, k, q, d, blockIdx.x*NW + wave, gridDim.x*NW);
+    if (KQ) {
+        char * rec = out + act_img_bytes(true, Ttot, k);
+        quant_q8K_to_lds<T, NW>(a, sc, k, q, d, bs, blockIdx.x*NW + wave, gridDim.x*NW, rec + (size_t) t0*nblk*32, rec + (size_t) Ttot*nblk*32 + (size_t) t0*nblk*32);
+    } else quant_q80_to_lds<T, NW>(a, sc, k, q, d, blockIdx.x*NW + wave, gridDim.x*NW);
 }
-template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src & a, int k, char * out) {
+template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src & a, int k, char * out, int Ttot, int t0) {
     const int units = T * ((k + 255) / 256);
     int grid = (units + 8*2 - 1) / (8*2); if (grid > 64) grid = 64; if (grid < 1) grid = 1;
     switch (T) {
-#define QA(n) case n: k_quant_act<KQ, n, 8><<<grid, 512, 0, st>>>(a, k, out); break;
+#define QA(n) case n: k_quant_act<KQ, n, 8><<<grid, 512, 0, st>>>(a, k, out, Ttot, t0); break;
         QA(1) QA(2) QA(3) QA(4) QA(5) QA(6) QA(7) QA(8)
 #undef QA
         default: MI_ABORT("quant_act: T=%d", T);
     }
 }
 size_t mi_act_image_bytes(int type, int T, int k) { return (act_img_bytes_full(mi_traits(type).blck == 256, T, k) + 255) & ~(size_t) 255; }
-void mi_quant_act(hipStream_t st, int type, int T, const act_src & a, int k, char * out) {
-    if (mi_traits(type).blck == 256) quant_act_T<true>(st, T, a, k, out); else quant_act_T<false>(st, T, a, k, out);
+void mi_quant_act(hipStream_t st, int type, int T, const act_src & a0, int k, char * out) {
+    for (int t0 = 0; t0 < T; t0 += 8) {                       // images of more than 8 tokens (matrix-core kernel) are filled 8 tokens per launch
+        act_src a = a0; a.X += (size_t) t0 * a.xs;
+        const int n = T - t0 < 8 ? T - t0 : 8;
+        if (mi_traits(type).blck == 256) quant_act_T<true>(st, n, a, k, out, T, t0); else quant_act_T<false>(st, n, a, k, out, T, t0);
+    }
 }
 
 // ---------------------------------------------------------------- host side
@@ -496,9 +504,15 @@ static int mmq_min_tokens() {
     return v;
 }
 void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_act_cache * cache, const void * key) {
-    const int tmax = mi_mmvq_max_tokens(type, L0.k);
+    int tmax = mi_mmvq_max_tokens(type, L0.k);
     MI_ASSERT(tmax >= 1);
     const int kq = mi_traits(type).blck == 256;
+    // big batches: the matrix-core kernel takes up to 32 tokens per pass (as many as its LDS image and the scratch slot allow)
+    if (cache && cache->pool && Ttot > tmax && Ttot >= mmq_min_tokens()) {
+        int tm = mi_mmq_max_tokens(type, L0.k, L0.swiglu != 0);
+        while (tm > 8 && mi_act_image_bytes(type, tm, L0.k) > cache->slot_bytes) tm -= 8;
+        if (tm > tmax && mi_mmq_supported(type, tm, L0.k, L0.swiglu != 0)) tmax = tm;
+    }
     for (int t0 = 0; t0 < Ttot; t0 += tmax) {
         const int T = (Ttot - t0) < tmax ? (Ttot - t0) : tmax;
         mmvq_launch L = L0;
@@ -506,7 +520,7 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
         L.act.pre = nullptr;
         for (int i = 0; i < L.n_mat; ++i) { L.m[i].out += (size_t) t0 * L.m[i].o_tok; if (L.m[i].res) L.m[i].res += (size_t) t0 * L.m[i].r_tok; }
         if (L.rope.pos) L.rope.pos += t0;
-        const bool mmq = cache && cache->pool && T >= mmq_min_tokens() && mi_mmq_supported(type, T, L.k) && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes;
+        const bool mmq = cache && cache->pool && T >= mmq_min_tokens() && mi_mmq_supported(type, T, L.k, L.swiglu != 0) && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes;
         if (cache && cache->pool && (mmq || (int64_t) T * L.k > PRE_MIN_ELEMS) && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes) {
             int hit = -1;
             if (key) for (int i = 0; i < MI_ACT_SLOTS; ++i) { const auto & e = cache->e[i]; if (e.key == key && e.epoch == cache->epoch && e.t0 == t0 && e.T == T && e.kq == kq && e.k == L.k) { hit = i; break; } }

@@ -99,7 +99,7 @@ __device__ __forceinline__ float4 fetch4(const act_src & a, const float * sc, in
 // Q8_K rule: the scale comes from the FIRST element of largest magnitude, iscale = -127/max,
 // q = min(127, rne(iscale*x)), d = 1/iscale, bsums over groups of 16.  One wave = one 256-element super-block;
 // loads for PB super-blocks are issued before the first reduction so their latencies overlap.
-template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, short * bs, int ubeg, int ustr, char * rec = nullptr) {
+template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, short * bs, int ubeg, int ustr, char * rec32 = nullptr, char * rec16 = nullptr) {
     const int lane = threadIdx.x % WAVE;
     const int nsb = k / 256, nu = T*nsb;
     constexpr int PB = 4;
@@ -131,8 +131,8 @@ template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const 
             s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s);
             if ((lane & 3) == 0) bs[t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
             if (lane == 0) d[t*nsb + sb] = dd;
-            if (rec) {                                                         // split sums for the matrix-core kernel
-                int8_t * r32 = (int8_t *) rec + (size_t)(t*nsb + sb)*32, * r16 = (int8_t *) rec + (size_t) T*nsb*32 + (size_t)(t*nsb + sb)*32;
+            if (rec32) {                                                       // split sums for the matrix-core kernel
+                int8_t * r32 = (int8_t *) rec32 + (size_t)(t*nsb + sb)*32, * r16 = (int8_t *) rec16 + (size_t)(t*nsb + sb)*32;
                 if ((lane & 3) == 0) { r16[lane >> 2] = (int8_t)(s & 127); r16[16 + (lane >> 2)] = (int8_t)(s >> 7); }
                 const int s2 = s + dpp_i<DPP_HMIR>(s);                          // quads are uniform: the other quad of the 8 lanes
                 if ((lane & 7) == 0) { r32[lane >> 3] = (int8_t)(s2 & 127); r32[16 + (lane >> 3)] = (int8_t)(s2 >> 7); }

@@ -16,7 +16,7 @@ def run(t, rows, k, T, mode, nrep=None):
     nrep = nrep or max(2, int(320e6 // per) + 1)
     g = ea.Graph(gpu)
     x = g.tensor(ea.F32, k, T); nw = g.tensor(ea.F32, k)
-    ws, outs = [], []
+    ws, outs, xs = [], [], []
     for i in range(nrep):
         if mode == "norm" or mode == "swiglu" or mode == "qkv":
             xin = g.mul(g.rms_norm(x, 1e-6), nw)
@@ -28,12 +28,16 @@ def run(t, rows, k, T, mode, nrep=None):
         elif mode == "qkv":
             a = g.tensor(t, k, rows); b = g.tensor(t, k, rows); c = g.tensor(t, k, rows); ws += [a, b, c]
             outs += [g.mul_mat(a, xin), g.mul_mat(b, xin), g.mul_mat(c, xin)]
+        elif mode == "single":      # one matrix per launch: own activations, so nothing is merged
+            xi = g.tensor(ea.F32, k, T); xs.append(xi)
+            a = g.tensor(t, k, rows); ws.append(a); outs.append(g.mul_mat(a, xi))
         else:
             a = g.tensor(t, k, rows); ws.append(a); outs.append(g.mul_mat(a, xin))
     g.alloc()
     blk = qdata.random_blocks(t, rows, k, rng)
     for w in ws: g.set(w, blk)
     g.set(x, rng.standard_normal((T, k)).astype(np.float32)); g.set(nw, np.ones(k, np.float32))
+    for xi in xs: g.set(xi, rng.standard_normal((T, k)).astype(np.float32))
     g.compute()
     best = None
     for it in range(3):
@@ -43,6 +47,11 @@ def run(t, rows, k, T, mode, nrep=None):
         if best is None or gbs > best[0]: best = (gbs, out[0] * 1e3 / n, n)
     print("%-5s rows %6d k %6d T %d %-7s launches %3d avg %7.2f us  %7.1f GB/s (%4.1f%% of 8 TB/s)" % (NAMES[t], rows, k, T, mode, best[2], best[1], best[0], best[0] / 80), flush=True)
 shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096)]
+if len(sys.argv) > 1 and sys.argv[1] == "single":      # the model's single-matrix launches (wo, ffn_down, lm_head) at T = 6
+    for t in (12, 14):
+        for rows, k in ((4096, 4096), (4096, 11008), (32000, 4096)): run(t, rows, k, 6, "single")
+    run(12, 11008, 4096, 6, "swiglu")
+    sys.exit(0)
 for T in (1, 6):
     for t in (12, 14):
         for rows, k in shapes:

@@ -75,7 +75,8 @@ def test_mul_mat_ragged_and_fused_residual(ea, gpu, tname):
     """rows not a multiple of the rows-per-block, k with a ragged last k-step, fused ADD epilogue, > 8 tokens"""
     t = QTYPES[tname]
     rng = np.random.default_rng(7)
-    for rows, k, T in [(1, 256, 1), (7, 768, 2), (33, 2816, 3), (130, 5120, 8), (50, 1024, 19)]:
+    # T > 8: K-quants take up to 24 tokens per pass (3 groups of 8 on the matrix cores): whole groups, ragged groups, several passes
+    for rows, k, T in [(1, 256, 1), (7, 768, 2), (33, 2816, 3), (130, 5120, 8), (50, 1024, 19), (40, 1024, 9), (48, 2048, 24), (21, 512, 61), (64, 4096, 128)]:
         w = qdata.random_blocks(t, rows, k, rng)
         x = rng.standard_normal((T, k)).astype(np.float32)
         res = rng.standard_normal((T, rows)).astype(np.float32)
