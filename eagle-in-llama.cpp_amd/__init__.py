@@ -71,6 +71,7 @@ def host():
             "eh_mul_mat": (vp, [vp, vp, vp]), "eh_rms_norm": (vp, [vp, vp, f32]), "eh_bin": (vp, [vp, i32, vp, vp]),
             "eh_unary": (vp, [vp, vp, i32]), "eh_scale": (vp, [vp, vp, f32]), "eh_concat": (vp, [vp, vp, vp, i32]),
             "eh_get_rows": (vp, [vp, vp, vp]),
+            "eh_argmax": (vp, [vp, vp]),
             "eh_rope": (vp, [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, f32]),
             "eh_soft_max": (vp, [vp, vp, vp, f32, f32]),
             "eh_alloc": (i32, [vp]), "eh_compute": (i32, [vp]),
@@ -194,6 +195,9 @@ class Graph:
 
     def get_rows(self, a, b):
         return host().eh_get_rows(self.h, a, b)
+
+    def argmax(self, a):
+        return host().eh_argmax(self.h, a)
 
     def rope(self, a, pos, n_dims, mode=0, ff=None, n_ctx_orig=0, freq_base=10000.0, freq_scale=1.0, ext_factor=0.0,
              attn_factor=1.0, beta_fast=32.0, beta_slow=1.0):

@@ -62,6 +62,8 @@ bool mi_supports_op(int, const ggml_tensor * op) {
             return is_f32(a) && is_f32(b) && is_f32(op);
         case GGML_OP_GET_ROWS:
             return (a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16) && b->type == GGML_TYPE_I32 && is_f32(op);
+        case GGML_OP_ARGMAX:
+            return is_f32(a) && a->nb[0] == 4 && a->ne[2] == 1 && a->ne[3] == 1 && op->type == GGML_TYPE_I32 && mi_is_contiguous(op) && a->ne[0] < (1ll << 31);
         case GGML_OP_ROPE: {
             const int mode = mi_op_i32(op, 2);
             if (mode != 0 && mode != GGML_ROPE_TYPE_NEOX) return false;
@@ -437,6 +439,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
             case GGML_OP_CONT: case GGML_OP_DUP: mi_op_cpy(st, t->src[0], t); break;
             case GGML_OP_CONCAT:   mi_op_concat(st, t); break;
             case GGML_OP_GET_ROWS: mi_op_get_rows(st, t); break;
+            case GGML_OP_ARGMAX:   mi_op_argmax(st, t); break;
             case GGML_OP_ROPE:     mi_op_rope(st, t); break;
             case GGML_OP_SOFT_MAX: mi_op_soft_max(st, t); break;
             default:

@@ -12,6 +12,7 @@ void mi_op_scale    (hipStream_t st, const ggml_tensor * dst);
 void mi_op_cpy      (hipStream_t st, const ggml_tensor * src, const ggml_tensor * dst); // CPY CONT DUP
 void mi_op_concat   (hipStream_t st, const ggml_tensor * dst);
 void mi_op_get_rows (hipStream_t st, const ggml_tensor * dst);
+void mi_op_argmax   (hipStream_t st, const ggml_tensor * dst);
 void mi_op_rope     (hipStream_t st, const ggml_tensor * dst);
 void mi_op_soft_max (hipStream_t st, const ggml_tensor * dst);
 // fused SwiGLU tail: dst = silu(gate) * up   (UNARY(SILU) followed by MUL)

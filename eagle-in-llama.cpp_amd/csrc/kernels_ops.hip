@@ -259,6 +259,34 @@ void mi_op_get_rows(hipStream_t st, const ggml_tensor * dst) {
     else MI_ABORT("get_rows: unsupported table type %d", t->type);
 }
 
+// ------------------------------------------------------------------ ARGMAX (f32 rows -> i32): first index of the largest value,
+// like ggml_vec_argmax_f32 (R/ggml/src/ggml-cpu/vec.h).  Greedy draft / verify steps fetch 4 bytes per token instead of a logits row.
+__global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, int32_t * __restrict__ dst, int64_t ne0, int64_t nb1) {
+    const float * row = (const float *)(x + (int64_t) blockIdx.x * nb1);
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int64_t i = threadIdx.x; i < ne0; i += 1024) { const float v = row[i]; if (v > best || (v == best && (int) i < bi)) { best = v; bi = (int) i; } }
+    if (bi == 0x7fffffff) bi = 0;                          // all NaN / -inf lanes fall back to index 0 like the CPU loop
+    __shared__ float sv[16]; __shared__ int si[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        dst[blockIdx.x] = bi;
+    }
+}
+void mi_op_argmax(hipStream_t st, const ggml_tensor * dst) {
+    const ggml_tensor * a = dst->src[0];
+    const int64_t rows = mi_nrows(a);
+    if (rows == 0) return;
+    k_argmax<<<(unsigned) rows, 1024, 0, st>>>((const char *) a->data, (int32_t *) dst->data, a->ne[0], a->nb[1]);
+}
+
 // ------------------------------------------------------------------ ROPE (mode NORM and NEOX, f32)
 struct rope_params {
     int n_dims; int mode; float freq_scale, ext_factor, attn_factor, theta_scale; float corr0, corr1;

@@ -42,6 +42,7 @@ EH_API void * eh_bin(void * c, int op, void * a, void * b) { return ((Ctx *) c)-
 EH_API void * eh_unary(void * c, void * a, int uop) { return ((Ctx *) c)->unary((ggml_tensor *) a, uop); }
 EH_API void * eh_scale(void * c, void * a, float s) { return ((Ctx *) c)->scale((ggml_tensor *) a, s); }
 EH_API void * eh_concat(void * c, void * a, void * b, int dim) { return ((Ctx *) c)->concat((ggml_tensor *) a, (ggml_tensor *) b, dim); }
+EH_API void * eh_argmax(void * c, void * a) { return ((Ctx *) c)->argmax((ggml_tensor *) a); }
 EH_API void * eh_get_rows(void * c, void * a, void * b) { return ((Ctx *) c)->get_rows((ggml_tensor *) a, (ggml_tensor *) b); }
 EH_API void * eh_rope(void * c, void * a, void * pos, void * ff, int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale,
                       float ext_factor, float attn_factor, float beta_fast, float beta_slow) {

@@ -13,6 +13,7 @@
 #include "model.h"
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #define EH_API extern "C" __attribute__((visibility("default")))
@@ -34,6 +35,8 @@ struct SpecState {
     int re_pos0 = 0;                // position of re_tok[0]
     Batch bt, bd;
     std::vector<int32_t> drafts;
+    bool fused_chain = getenv("EH_STEPWISE_DRAFT") == nullptr;
+    bool device_argmax = getenv("EH_HOST_ARGMAX") == nullptr;      // EH_HOST_ARGMAX=1: fetch the logits and take the arg-max on the host like the reference's sampler
 };
 
 // prompt: target over all tokens (features for the draft), draft over tokens 1..n-1
@@ -73,14 +76,29 @@ static int spec_draft(SpecState & s, int n_draft, float p_min, double * st) {
     const int nre = (int) s.re_tok.size();
     for (int i = 0; i < nre; ++i) d.add(s.re_tok[i], s.re_pos0 + i, 0, i == nre - 1);
     d.hidd = s.re_feat;
+    // greedy without a confidence cut-off: the whole chain runs as ONE graph with the token / feature hand-off on the device
+    // (Model::decode_chain); EH_STEPWISE_DRAFT=1 keeps the reference's one-decode-per-step loop
+    if (s.fused_chain && p_min <= 0.0f && n_draft > 1 && D.cfg.tp_size == 1) {
+        std::vector<int32_t> ids;
+        const int rc = D.decode_chain(d, n_draft, ids);
+        if (rc == 0) {
+            st[ST_N_DRAFT_CALLS] += 1; st[ST_N_DRAFTED] += n_draft;
+            s.drafts = ids;
+            st[ST_T_DRAFT_US] += now_us() - t0;
+            return (int) s.drafts.size();
+        }
+        if (rc < 0) return -10 + rc;                       // rc == 1 (no KV room for the whole chain): fall through to the stepwise loop
+    }
+    // greedy without a confidence cut-off only needs the arg-max token: it is computed on the device (GGML_OP_ARGMAX appended to
+    // the graph) and 4 bytes come back instead of a 128 KB logits row; p_min > 0 needs the probabilities, hence the logits
+    D.want_logits = p_min > 0.0f || !s.device_argmax;
     for (int j = 0; j < n_draft; ++j) {
         int rc = D.decode(d, true);
         st[ST_N_DRAFT_CALLS] += 1;
         if (rc) return -10 - rc;
         const int last = d.n_tokens() - 1;
-        const float * lg = D.logits_ith(last);
-        const int id = argmax(lg, V);
-        if (p_min > 0.0f && top_prob(lg, V, id) < p_min) break;
+        const int id = D.argmax_ith(last);
+        if (p_min > 0.0f && top_prob(D.logits_ith(last), V, id) < p_min) break;
         s.drafts.push_back(id);
         st[ST_N_DRAFTED] += 1;
         if (j + 1 == n_draft) break;
@@ -89,25 +107,28 @@ static int spec_draft(SpecState & s, int n_draft, float p_min, double * st) {
         std::vector<float> feat(g, g + E);
         d.clear(); d.add(id, pos, 0, true); d.hidd = std::move(feat);
     }
+    D.want_logits = true;
     st[ST_T_DRAFT_US] += now_us() - t0;
     return (int) s.drafts.size();
 }
 // verify + accept + bookkeeping of a round; returns number of new tokens appended to out (>= 1) or < 0 on error
 static int spec_verify(SpecState & s, int32_t * out, double * st) {
     Model & T = *s.tgt;
-    const int E = T.cfg.n_embd, V = T.cfg.n_vocab;
+    const int E = T.cfg.n_embd;
     const double t1 = now_us();
     // ---- verify: [id_last, drafts...] in one target batch, logits for every token
     Batch & b = s.bt; b.clear();
     b.add(s.id_last, s.n_past, 0, true);
     for (size_t i = 0; i < s.drafts.size(); ++i) b.add(s.drafts[i], s.n_past + 1 + (int) i, 0, true);
+    T.want_logits = !s.device_argmax;
     int rc = T.decode(b, true);
+    T.want_logits = true;
     st[ST_N_TARGET_CALLS] += 1;
     if (rc) return -20 - rc;
     // ---- accept (greedy)
     int m = 0, n_out = 0;
     for (;;) {
-        const int tok = argmax(T.logits_ith(m), V);
+        const int tok = T.argmax_ith(m);
         out[n_out++] = tok;
         if (m < (int) s.drafts.size() && tok == s.drafts[m]) { m++; continue; }
         break;

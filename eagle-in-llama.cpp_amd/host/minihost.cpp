@@ -187,6 +187,7 @@ ggml_tensor * Ctx::concat(ggml_tensor * a, ggml_tensor * b, int dim) {
     ggml_tensor * r = op_result(GGML_OP_CONCAT, a->type, ne, a, b); r->op_params[0] = dim; return r;
 }
 ggml_tensor * Ctx::get_rows(ggml_tensor * a, ggml_tensor * b) { int64_t ne[4] = {a->ne[0], b->ne[0], b->ne[1], b->ne[2]}; return op_result(GGML_OP_GET_ROWS, GGML_TYPE_F32, ne, a, b); }
+ggml_tensor * Ctx::argmax(ggml_tensor * a) { int64_t ne[4] = {a->ne[1], 1, 1, 1}; return op_result(GGML_OP_ARGMAX, GGML_TYPE_I32, ne, a); }
 ggml_tensor * Ctx::rope_ext(ggml_tensor * a, ggml_tensor * pos, ggml_tensor * ff, int n_dims, int mode, int n_ctx_orig,
                             float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow) {
     ggml_tensor * r = op_result(GGML_OP_ROPE, a->type, a->ne, a, pos, ff);

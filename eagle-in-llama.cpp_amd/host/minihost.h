@@ -97,6 +97,7 @@ struct Ctx {
     ggml_tensor * scale(ggml_tensor * a, float s);
     ggml_tensor * concat(ggml_tensor * a, ggml_tensor * b, int dim);
     ggml_tensor * get_rows(ggml_tensor * a, ggml_tensor * b);
+    ggml_tensor * argmax(ggml_tensor * a);        // ggml_argmax: i32 [ne1] indices of the row maxima of a 2-D tensor
     ggml_tensor * rope_ext(ggml_tensor * a, ggml_tensor * pos, ggml_tensor * ff, int n_dims, int mode, int n_ctx_orig,
                            float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow);
     ggml_tensor * soft_max_ext(ggml_tensor * a, ggml_tensor * mask, float scale, float max_bias);

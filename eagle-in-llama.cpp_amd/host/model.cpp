@@ -180,7 +180,7 @@ Model::~Model() { if (stage_in && be) { be->synchronize(); be->host_free(stage_i
 
 Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const SynthOptions & opt, const Model * target) {
     Model * m = new Model;
-    m->cfg = cfg; m->be = be; m->logits.be = be; m->hidden.be = be;
+    m->cfg = cfg; m->be = be; m->logits.be = be; m->hidden.be = be; m->ids_stage.be = be;
     m->wctx.reset(new mh::Ctx(be)); m->wctx->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
     m->gctx.reset(new mh::Ctx(be)); m->gctx->usage = GGML_BACKEND_BUFFER_USAGE_COMPUTE;
     mh::Ctx & w = *m->wctx;
@@ -301,6 +301,86 @@ Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const
     return m;
 }
 
+// ------------------------------------------------------------------ graph of one forward pass (build_llama :1647 / build_eagle :1839)
+void Model::build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<Cut> * cuts,
+                          ggml_tensor *& result_norm, ggml_tensor *& result_output, ggml_tensor *& result_argmax) {
+    const int E = cfg.n_embd, H = n_head_local, Hkv = n_head_kv_local, D = cfg.head_dim, n_ctx = cfg.n_ctx;
+    const int KVd = Hkv * D;
+    (void) E;
+    ggml_tensor * inpL = io.embd, * cur;
+    if (cfg.eagle) {                                           // build_eagle :1863-1870
+        ggml_tensor * embd_hs = g.concat(io.embd, io.hidd, 0);
+        cur = g.mul_mat(fc, embd_hs);
+        if (fc_b) cur = g.add(cur, fc_b);
+        inpL = g.unary(cur, GGML_UNARY_OP_RELU);
+    }
+    const float kq_scale = 1.0f / sqrtf((float) D);
+    char nm[64];
+    int n_tok = io.T;
+    for (int il = 0; il < cfg.n_layer; ++il) {
+        const Layer & L = layers[il];
+        ggml_tensor * inpSA = inpL;
+        cur = g.rms_norm(inpL, cfg.rms_eps);
+        if (L.attn_norm) cur = g.mul(cur, L.attn_norm);
+        snprintf(nm, sizeof nm, "attn_norm-%d", il); g.set_name(cur, nm);
+        ggml_tensor * Qcur = g.mul_mat(L.wq, cur);
+        Qcur = g.rope_ext(g.reshape(Qcur, D, H, n_tok), io.pos, nullptr, D, 0, 0, cfg.rope_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
+        snprintf(nm, sizeof nm, "Qcur-%d", il); g.set_name(Qcur, nm);
+        ggml_tensor * Kcur = g.mul_mat(L.wk, cur);
+        Kcur = g.rope_ext(g.reshape(Kcur, D, Hkv, n_tok), io.pos, nullptr, D, 0, 0, cfg.rope_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
+        snprintf(nm, sizeof nm, "Kcur-%d", il); g.set_name(Kcur, nm);
+        ggml_tensor * Vcur = g.mul_mat(L.wv, cur);
+        snprintf(nm, sizeof nm, "Vcur-%d", il); g.set_name(Vcur, nm);
+        // llm_build_kv_store :228-270
+        ggml_tensor * k_view = g.view_1d(k_l[il], (int64_t) n_tok * KVd, (size_t) KVd * 2 * io.kv_head);
+        g.cpy(Kcur, k_view);
+        ggml_tensor * v_view = g.view_2d(v_l[il], n_tok, KVd, (size_t) n_ctx * 2, (size_t) io.kv_head * 2);
+        g.cpy(g.transpose(Vcur), v_view);
+        // llm_build_kqv :706-828 (no flash attention)
+        ggml_tensor * q = g.permute(Qcur, 0, 2, 1, 3);
+        ggml_tensor * k = g.view_3d(k_l[il], D, io.n_kv, Hkv, (size_t) KVd * 2, (size_t) D * 2, 0);
+        ggml_tensor * kq = g.mul_mat(k, q);
+        kq->op_params[0] = GGML_PREC_F32;
+        kq = g.soft_max_ext(kq, io.mask, kq_scale, 0.0f);
+        ggml_tensor * v = g.view_3d(v_l[il], io.n_kv, D, Hkv, (size_t) n_ctx * 2, (size_t) n_ctx * D * 2, 0);
+        ggml_tensor * kqv = g.mul_mat(v, kq);
+        cur = g.cont_2d(g.permute(kqv, 0, 2, 1, 3), (int64_t) D * H, n_tok);
+        cur = g.mul_mat(L.wo, cur);                            // TP: partial sum over this rank's heads
+        if (tp && cuts) cuts->push_back({ (int) g.nodes.size(), cur });
+        if (il == cfg.n_layer - 1) {                           // skip unused tokens :1737-1743
+            n_tok = io.n_outputs;
+            cur = g.get_rows(cur, io.out_ids);
+            inpSA = g.get_rows(inpSA, io.out_ids);
+        }
+        ggml_tensor * ffn_inp = g.add(cur, inpSA);
+        cur = g.rms_norm(ffn_inp, cfg.rms_eps);
+        cur = g.mul(cur, L.ffn_norm);
+        ggml_tensor * gate = g.mul_mat(L.gate, cur);             // llm_build_ffn, LLM_FFN_SILU / LLM_FFN_PAR, in DFS order
+        gate = g.unary(gate, GGML_UNARY_OP_SILU);
+        ggml_tensor * up = g.mul_mat(L.up, cur);
+        cur = g.mul(gate, up);
+        cur = g.mul_mat(L.down, cur);                          // TP: partial sum over this rank's slice of n_ff
+        if (tp && cuts) cuts->push_back({ (int) g.nodes.size(), cur });
+        cur = g.add(cur, ffn_inp);
+        snprintf(nm, sizeof nm, "l_out-%d", il); g.set_name(cur, nm);
+        inpL = cur;
+    }
+    result_norm = nullptr; result_output = nullptr; result_argmax = nullptr;
+    const bool head_here = !tp || cfg.tp_rank == 0;          // TP: the LM head (and the hidden-state channel) live on rank 0
+    if (head_here) {
+        cur = g.rms_norm(inpL, cfg.rms_eps);
+        if (output_norm) cur = g.mul(cur, output_norm);
+        g.set_name(cur, "result_norm");
+        result_norm = cur;
+        ggml_tensor * head = cfg.eagle ? lm_head_from->output : output;
+        cur = g.mul_mat(head, cur);
+        g.set_name(cur, "result_output");
+        result_output = cur;
+        result_norm->flags |= GGML_TENSOR_FLAG_OUTPUT; result_output->flags |= GGML_TENSOR_FLAG_OUTPUT;
+        if (!want_logits) { result_argmax = g.argmax(result_output); g.set_name(result_argmax, "result_argmax"); result_argmax->flags |= GGML_TENSOR_FLAG_OUTPUT; }
+    }
+}
+
 // ------------------------------------------------------------------ decode
 int Model::decode(const Batch & b, bool want_hidden) {
     const double t0 = now_us();
@@ -314,10 +394,8 @@ int Model::decode(const Batch & b, bool want_hidden) {
     static const bool force_tp = getenv("EH_FORCE_TP") != nullptr;     // run the segmented path + collectives even with one rank (single-GPU rehearsal)
     const bool tp = cfg.tp_size > 1 || (force_tp && allreduce && !cfg.eagle);
     if (tp && !allreduce) return -5;
-    const int E = cfg.n_embd, H = n_head_local, Hkv = n_head_kv_local, D = cfg.head_dim, n_ctx = cfg.n_ctx;
-    struct Cut { int node_end; ggml_tensor * t; };
+    const int E = cfg.n_embd;
     std::vector<Cut> cuts;                                   // tensor parallel: partial sums to all-reduce, and where the graph is cut
-    const int KVd = Hkv * D;
     n_outputs = 0; out_ids.clear();
     for (int i = 0; i < T; ++i) if (b.logits[i]) { out_ids.push_back(i); n_outputs++; }
     if (n_outputs == 0) { out_ids.push_back(T - 1); n_outputs = 1; }
@@ -332,77 +410,10 @@ int Model::decode(const Batch & b, bool want_hidden) {
     ggml_tensor * inp_out  = g.new_tensor(GGML_TYPE_I32, n_outputs, 1, 1, 1, "inp_out_ids");
     for (ggml_tensor * t : {inp_embd, inp_hidd, inp_pos, kq_mask, inp_out}) if (t) t->flags |= GGML_TENSOR_FLAG_INPUT;
 
-    ggml_tensor * inpL = inp_embd, * cur;
-    if (cfg.eagle) {                                           // build_eagle :1863-1870
-        ggml_tensor * embd_hs = g.concat(inp_embd, inp_hidd, 0);
-        cur = g.mul_mat(fc, embd_hs);
-        if (fc_b) cur = g.add(cur, fc_b);
-        inpL = g.unary(cur, GGML_UNARY_OP_RELU);
-    }
-    const float kq_scale = 1.0f / sqrtf((float) D);
-    char nm[64];
-    int n_tok = T;
-    for (int il = 0; il < cfg.n_layer; ++il) {
-        const Layer & L = layers[il];
-        ggml_tensor * inpSA = inpL;
-        cur = g.rms_norm(inpL, cfg.rms_eps);
-        if (L.attn_norm) cur = g.mul(cur, L.attn_norm);
-        snprintf(nm, sizeof nm, "attn_norm-%d", il); g.set_name(cur, nm);
-        ggml_tensor * Qcur = g.mul_mat(L.wq, cur);
-        Qcur = g.rope_ext(g.reshape(Qcur, D, H, n_tok), inp_pos, nullptr, D, 0, 0, cfg.rope_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
-        snprintf(nm, sizeof nm, "Qcur-%d", il); g.set_name(Qcur, nm);
-        ggml_tensor * Kcur = g.mul_mat(L.wk, cur);
-        Kcur = g.rope_ext(g.reshape(Kcur, D, Hkv, n_tok), inp_pos, nullptr, D, 0, 0, cfg.rope_base, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f);
-        snprintf(nm, sizeof nm, "Kcur-%d", il); g.set_name(Kcur, nm);
-        ggml_tensor * Vcur = g.mul_mat(L.wv, cur);
-        snprintf(nm, sizeof nm, "Vcur-%d", il); g.set_name(Vcur, nm);
-        // llm_build_kv_store :228-270
-        ggml_tensor * k_view = g.view_1d(k_l[il], (int64_t) n_tok * KVd, (size_t) KVd * 2 * kv_head);
-        g.cpy(Kcur, k_view);
-        ggml_tensor * v_view = g.view_2d(v_l[il], n_tok, KVd, (size_t) n_ctx * 2, (size_t) kv_head * 2);
-        g.cpy(g.transpose(Vcur), v_view);
-        // llm_build_kqv :706-828 (no flash attention)
-        ggml_tensor * q = g.permute(Qcur, 0, 2, 1, 3);
-        ggml_tensor * k = g.view_3d(k_l[il], D, n_kv, Hkv, (size_t) KVd * 2, (size_t) D * 2, 0);
-        ggml_tensor * kq = g.mul_mat(k, q);
-        kq->op_params[0] = GGML_PREC_F32;
-        kq = g.soft_max_ext(kq, kq_mask, kq_scale, 0.0f);
-        ggml_tensor * v = g.view_3d(v_l[il], n_kv, D, Hkv, (size_t) n_ctx * 2, (size_t) n_ctx * D * 2, 0);
-        ggml_tensor * kqv = g.mul_mat(v, kq);
-        cur = g.cont_2d(g.permute(kqv, 0, 2, 1, 3), (int64_t) D * H, n_tok);
-        cur = g.mul_mat(L.wo, cur);                            // TP: partial sum over this rank's heads
-        if (tp) cuts.push_back({ (int) g.nodes.size(), cur });
-        if (il == cfg.n_layer - 1) {                           // skip unused tokens :1737-1743
-            n_tok = n_outputs;
-            cur = g.get_rows(cur, inp_out);
-            inpSA = g.get_rows(inpSA, inp_out);
-        }
-        ggml_tensor * ffn_inp = g.add(cur, inpSA);
-        cur = g.rms_norm(ffn_inp, cfg.rms_eps);
-        cur = g.mul(cur, L.ffn_norm);
-        ggml_tensor * gate = g.mul_mat(L.gate, cur);             // llm_build_ffn, LLM_FFN_SILU / LLM_FFN_PAR, in DFS order
-        gate = g.unary(gate, GGML_UNARY_OP_SILU);
-        ggml_tensor * up = g.mul_mat(L.up, cur);
-        cur = g.mul(gate, up);
-        cur = g.mul_mat(L.down, cur);                          // TP: partial sum over this rank's slice of n_ff
-        if (tp) cuts.push_back({ (int) g.nodes.size(), cur });
-        cur = g.add(cur, ffn_inp);
-        snprintf(nm, sizeof nm, "l_out-%d", il); g.set_name(cur, nm);
-        inpL = cur;
-    }
-    ggml_tensor * result_norm = nullptr, * result_output = nullptr;
+    StepIO io{ inp_embd, inp_hidd, inp_pos, kq_mask, inp_out, T, n_outputs, n_kv, kv_head };
+    ggml_tensor * result_norm = nullptr, * result_output = nullptr, * result_argmax = nullptr;
+    build_forward(g, io, tp, &cuts, result_norm, result_output, result_argmax);
     const bool head_here = !tp || cfg.tp_rank == 0;          // TP: the LM head (and the hidden-state channel) live on rank 0
-    if (head_here) {
-        cur = g.rms_norm(inpL, cfg.rms_eps);
-        if (output_norm) cur = g.mul(cur, output_norm);
-        g.set_name(cur, "result_norm");
-        result_norm = cur;
-        ggml_tensor * head = cfg.eagle ? lm_head_from->output : output;
-        cur = g.mul_mat(head, cur);
-        g.set_name(cur, "result_output");
-        result_output = cur;
-        result_norm->flags |= GGML_TENSOR_FLAG_OUTPUT; result_output->flags |= GGML_TENSOR_FLAG_OUTPUT;
-    }
     last_n_nodes = (int) g.nodes.size();
     if (!g.alloc()) return -3;
     const double t1 = now_us();
@@ -461,7 +472,12 @@ int Model::decode(const Batch & b, bool want_hidden) {
         if (st == GGML_STATUS_SUCCESS) st = g.compute_range(n0, (int) g.nodes.size());
     }
     const double t3a = now_us();
-    if (st == GGML_STATUS_SUCCESS && head_here) {
+    if (st == GGML_STATUS_SUCCESS && head_here && result_argmax) {
+        logits.clear();
+        if (ids_stage.size() < (size_t) n_outputs) ids_stage.resize((size_t) n_outputs + 64);
+        g.get_async(result_argmax, ids_stage.data(), 0, (size_t) n_outputs * 4);
+        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(result_norm, hidden.data(), 0, hidden.size() * 4); }
+    } else if (st == GGML_STATUS_SUCCESS && head_here) {
         logits.resize((size_t) n_outputs * cfg.n_vocab);
         g.get_async(result_output, logits.data(), 0, logits.size() * 4);
         if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(result_norm, hidden.data(), 0, hidden.size() * 4); }
@@ -470,10 +486,136 @@ int Model::decode(const Batch & b, bool want_hidden) {
     const double t3 = now_us();
     g.t_issue_us += t3a - t2; g.t_wait_us += t3 - t3a;
     if (st != GGML_STATUS_SUCCESS) { return st == GGML_STATUS_ABORTED ? 2 : -4; }
+    argmax_ids.clear();
+    if (head_here && result_argmax) { const int32_t * p = (const int32_t *) ids_stage.data(); argmax_ids.assign(p, p + n_outputs); }
     kv.head += T;
     if (kv.head >= kv.size) kv.head = 0;
     const double t4 = now_us();
     t_build_us += t1 - t0; t_upload_us += t2 - t1; t_compute_us += t3 - t2; t_download_us += t4 - t3; n_decode++;
+    return 0;
+}
+
+int Model::argmax_ith(int i) const {
+    for (int r = 0; r < n_outputs; ++r) if (out_ids[r] == i) {
+        if (!argmax_ids.empty()) return argmax_ids[r];
+        if (logits.size() == 0) return -1;
+        const float * v = logits.data() + (size_t) r * cfg.n_vocab; int b = 0; float m = v[0];
+        for (int j = 1; j < cfg.n_vocab; ++j) if (v[j] > m) { m = v[j]; b = j; }
+        return b;
+    }
+    return -1;
+}
+// ------------------------------------------------------------------ fused greedy draft chain
+int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> & ids) {
+    const double t0 = now_us();
+    ids.clear();
+    const int T0 = first.n_tokens(), E = cfg.n_embd;
+    if (!cfg.eagle || cfg.tp_size > 1 || T0 <= 0 || n_steps < 1) return -1;
+    if ((int) first.hidd.size() != T0 * E) return -2;
+    if (!tok_embd_dev) {                                       // the reference keeps token_embd on the host; the fused loop needs it next to the arg-max
+        ectx.reset(new mh::Ctx(be)); ectx->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+        tok_embd_dev = ectx->new_tensor(GGML_TYPE_F16, E, cfg.n_vocab, 1, 1, "token_embd.weight");
+        if (!ectx->alloc()) { tok_embd_dev = nullptr; ectx.reset(); return -3; }
+        ectx->set(tok_embd_dev, tok_embd.data(), 0, tok_embd.size() * 2);
+    }
+    // ---- KV slots of every step (positions are known in advance: a chain)
+    std::vector<Batch> bs(n_steps);
+    std::vector<int> heads(n_steps);
+    bs[0] = first;
+    const int32_t pos_last = first.pos[T0 - 1], seq = first.seq_first[T0 - 1];
+    const KVCache kv_saved = kv;
+    for (int j = 0; j < n_steps; ++j) {
+        if (j > 0) { bs[j].clear(); bs[j].add(0, pos_last + j, seq, true); }
+        if (!kv.find_slot(bs[j])) { kv = kv_saved; return 1; }
+        heads[j] = (int) kv.head;
+        kv.head += bs[j].n_tokens(); if (kv.head >= kv.size) kv.head = 0;
+    }
+    const uint32_t pad = 32;
+    kv.n = std::min(kv.size, std::max(pad, (kv.cell_max() + pad - 1) / pad * pad));
+    const int n_kv = (int) kv.n;
+
+    mh::Ctx & g = *gctx;
+    g.reset_graph();
+    // ---- inputs of all steps first (they go up as one copy), then the graphs
+    struct In { ggml_tensor * embd, * hidd, * pos, * mask, * out; int T, Tpad; };
+    std::vector<In> in(n_steps);
+    std::vector<ggml_tensor *> inputs;
+    for (int j = 0; j < n_steps; ++j) {
+        const int T = bs[j].n_tokens(), Tpad = (T + GGML_KQ_MASK_PAD - 1) / GGML_KQ_MASK_PAD * GGML_KQ_MASK_PAD;
+        in[j].T = T; in[j].Tpad = Tpad;
+        in[j].embd = j == 0 ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd") : nullptr;
+        in[j].hidd = j == 0 ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_hidd") : nullptr;
+        in[j].pos  = g.new_tensor(GGML_TYPE_I32, T, 1, 1, 1, "inp_pos");
+        in[j].mask = g.new_tensor(GGML_TYPE_F32, n_kv, Tpad, 1, 1, "KQ_mask");
+        in[j].out  = g.new_tensor(GGML_TYPE_I32, 1, 1, 1, 1, "inp_out_ids");
+        for (ggml_tensor * t : { in[j].embd, in[j].hidd, in[j].pos, in[j].mask, in[j].out }) if (t) { t->flags |= GGML_TENSOR_FLAG_INPUT; inputs.push_back(t); }
+    }
+    const bool saved_want = want_logits;
+    want_logits = false;                                        // every step ends in GGML_OP_ARGMAX
+    std::vector<ggml_tensor *> amax(n_steps);
+    ggml_tensor * prev_norm = nullptr;
+    for (int j = 0; j < n_steps; ++j) {
+        ggml_tensor * embd = in[j].embd, * hidd = in[j].hidd;
+        if (j > 0) { embd = g.get_rows(tok_embd_dev, amax[j - 1]); hidd = prev_norm; }     // the hand-off never leaves the device
+        StepIO io{ embd, hidd, in[j].pos, in[j].mask, in[j].out, in[j].T, 1, n_kv, heads[j] };
+        ggml_tensor * rn = nullptr, * ro = nullptr, * ra = nullptr;
+        build_forward(g, io, false, nullptr, rn, ro, ra);
+        amax[j] = ra; prev_norm = rn;
+    }
+    want_logits = saved_want;
+    last_n_nodes = (int) g.nodes.size();
+    if (!g.alloc()) { kv = kv_saved; return -3; }
+    const double t1 = now_us();
+
+    // ---- host image of the inputs, one asynchronous copy
+    ggml_tensor * base = inputs[0];
+    size_t span = 0; bool packed = true;
+    for (ggml_tensor * t : inputs) {
+        const ptrdiff_t off = (char *) t->data - (char *) base->data;
+        if (t->buffer != base->buffer || off < 0 || (size_t) off > ((size_t) 64 << 20)) { packed = false; break; }
+        span = std::max(span, (size_t) off + mh::nbytes(t));
+    }
+    if (packed && span > stage_cap) {
+        if (stage_in) { be->synchronize(); be->host_free(stage_in); }
+        stage_cap = span + span/2 + 4096; stage_in = (char *) be->host_alloc(stage_cap);
+    }
+    static thread_local std::vector<char> unpacked;
+    auto host_of = [&](ggml_tensor * t) -> char * { if (packed) return stage_in + ((char *) t->data - (char *) base->data); unpacked.resize(mh::nbytes(t)); return unpacked.data(); };
+    auto flush = [&](ggml_tensor * t, char * h) { if (!packed) g.set(t, h, 0, mh::nbytes(t)); };
+    for (int j = 0; j < n_steps; ++j) {
+        const Batch & b = bs[j]; const int T = in[j].T;
+        if (in[j].embd) {
+            float * embd = (float *) host_of(in[j].embd);
+            for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; float * dst = embd + (size_t) i * E; for (int q = 0; q < E; ++q) dst[q] = h2f(src[q]); }
+            flush(in[j].embd, (char *) embd);
+            char * h = host_of(in[j].hidd); memcpy(h, b.hidd.data(), (size_t) T * E * 4); flush(in[j].hidd, h);
+        }
+        { char * h = host_of(in[j].pos); memcpy(h, b.pos.data(), (size_t) T * 4); flush(in[j].pos, h); }
+        { int32_t last = T - 1; char * h = host_of(in[j].out); memcpy(h, &last, 4); flush(in[j].out, h); }
+        float * mask = (float *) host_of(in[j].mask);
+        std::fill(mask, mask + (size_t) n_kv * in[j].Tpad, -INFINITY);
+        for (int r = 0; r < T; ++r) {
+            const uint64_t sbit = 1ull << b.seq_first[r]; const int32_t pos = b.pos[r];
+            float * row = mask + (size_t) r * n_kv;
+            for (int i = 0; i < n_kv; ++i) if ((kv.cells[i].seqs & sbit) && kv.cells[i].pos <= pos) row[i] = 0.0f;
+        }
+        flush(in[j].mask, (char *) mask);
+    }
+    if (packed) g.set_async(base, stage_in, 0, span);
+    const double t2 = now_us();
+
+    enum ggml_status st = g.compute_async();
+    const double t3a = now_us();
+    if (ids_stage.size() < (size_t) n_steps) ids_stage.resize((size_t) n_steps + 64);
+    if (st == GGML_STATUS_SUCCESS) for (int j = 0; j < n_steps; ++j) g.get_async(amax[j], (int32_t *) ids_stage.data() + j, 0, 4);
+    be->synchronize();
+    const double t3 = now_us();
+    g.t_issue_us += t3a - t2; g.t_wait_us += t3 - t3a;
+    if (st != GGML_STATUS_SUCCESS) { kv = kv_saved; return st == GGML_STATUS_ABORTED ? 2 : -4; }
+    const int32_t * p = (const int32_t *) ids_stage.data();
+    ids.assign(p, p + n_steps);
+    logits.clear(); hidden.clear(); argmax_ids.clear(); n_outputs = 0; out_ids.clear();
+    t_build_us += t1 - t0; t_upload_us += t2 - t1; t_compute_us += t3 - t2; n_decode++;
     return 0;
 }
 

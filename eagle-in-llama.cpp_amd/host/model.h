@@ -84,9 +84,15 @@ struct Model {
     // outputs of the last decode
     mh::HostVec logits;               // [n_outputs][n_vocab]   page-locked: the device writes it with an async copy
     mh::HostVec hidden;               // [n_outputs][n_embd]    (result_norm rows: the hidden-state channel)
+    mh::HostVec ids_stage;            // page-locked landing zone of the argmax ids (int32 stored in float slots)
     char * stage_in = nullptr; size_t stage_cap = 0;   // page-locked image of the input tensors of one decode
     std::vector<int32_t> out_ids;     // batch index of each output row
     int n_outputs = 0;
+    // greedy fast path: with want_logits = false decode() appends GGML_OP_ARGMAX to the graph and brings back one int per output
+    // row (`argmax_ids`) instead of the logits rows; logits stays empty then
+    bool want_logits = true;
+    std::vector<int32_t> argmax_ids;  // [n_outputs], valid after every decode on the rank that owns the LM head
+    int argmax_ith(int i) const;      // by batch index; falls back to scanning logits when they were downloaded
     // timing / stats
     double t_build_us = 0, t_upload_us = 0, t_compute_us = 0, t_download_us = 0; int64_t n_decode = 0;
     int last_n_nodes = 0;
@@ -95,9 +101,21 @@ struct Model {
     ~Model();
     // llama_decode / llama_decode_draft: 0 ok, 1 no KV slot, <0 error (R/src/llama.cpp:9610-9617)
     int decode(const Batch & batch, bool want_hidden);
+    // EAGLE head only, greedy: `n_steps` autoregressive draft steps as ONE graph (device-resident hand-off).  Step 0 is
+    // `first` (accepted tokens + target features from the host); step j >= 1 feeds the device-side arg-max token of step j-1
+    // (GGML_OP_ARGMAX -> GET_ROWS on a device copy of token_embd) and its result_norm row straight back in.  One upload, one
+    // synchronize, n_steps ints come back.  Returns 0 and fills `ids`; 1 when the KV cache has no room (caller falls back).
+    int decode_chain(const Batch & first, int n_steps, std::vector<int32_t> & ids);
     const float * logits_ith(int i) const;      // by batch index, like llama_get_logits_ith
     const float * hidden_ith(int i) const;
     size_t matmul_weight_bytes() const { return weight_bytes; }
+
+    struct Cut { int node_end; ggml_tensor * t; };          // tensor parallel: partial sums to all-reduce, and where the graph is cut
+    struct StepIO { ggml_tensor * embd, * hidd, * pos, * mask, * out_ids; int T, n_outputs, n_kv, kv_head; };
+    void build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<Cut> * cuts,
+                       ggml_tensor *& result_norm, ggml_tensor *& result_output, ggml_tensor *& result_argmax);
+    std::unique_ptr<mh::Ctx> ectx;    // device copy of token_embd (f16 [n_embd, n_vocab]), created on the first decode_chain
+    ggml_tensor * tok_embd_dev = nullptr;
 };
 
 // per-type byte size of a row

@@ -34,7 +34,7 @@ int main() {
     (void) hipMemset(buf, 1, total + 4096);
     hipEvent_t e0, e1; (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
     const int grid = 512, waves = grid * 8;
-    for (int layout = 0; layout < 2; ++layout) for (int stride : {8192, 9030 & ~1, 3360}) for (int off : {0, 2, 4, 8}) {
+    for (int layout = 0; layout < 2; ++layout) for (int stride : {8192, 9030, 9028, 9032, 6192, 3360}) for (int off : {0, 2, 4, 8}) {
         if (layout == 0 && stride != 8192) continue;
         const size_t per_wave = layout == 0 ? ((total / waves) & ~(size_t) 4095) : (size_t) 16 * stride;
         const int g = layout == 0 ? grid : (int) (total / per_wave / 8);

@@ -92,3 +92,22 @@ def test_speculative_tokens_and_acceptance_identical(ea, gpu, ref_cpu, ftype):
         d.close(); t.close()
     assert seqs[0] == seqs[1]                                 # accepted-token indices bit-exact vs the reference CPU path
     assert seqs[0][1] > 0
+
+
+@pytest.mark.gpu
+def test_fused_draft_chain_equals_stepwise(ea, gpu, monkeypatch):
+    """Model::decode_chain (the n_draft steps of a round as ONE graph: device-side ARGMAX -> GET_ROWS(token_embd) and the
+    result_norm row fed straight back) must draft exactly what the reference-style loop (one decode, one host arg-max per
+    step) drafts: same tokens, same accept counts, same number of rounds."""
+    res = []
+    for stepwise in (False, True):
+        if stepwise: monkeypatch.setenv("EH_STEPWISE_DRAFT", "1")
+        else: monkeypatch.delenv("EH_STEPWISE_DRAFT", raising=False)
+        t = ea.Model(gpu, "tiny", "q4_k_m", n_ctx=512, seed=11)
+        d = ea.Model(gpu, "tiny", "q4_k_m", n_ctx=512, eagle_of=t, seed=11, accept_p=0.75)
+        prompt = [int(x) for x in np.random.default_rng(99).integers(5, 512, 24)]
+        spec, st = ea.spec_generate(t, d, prompt, 80, n_draft=5)
+        res.append((spec, st["n_accept"], st["n_drafted"], st["n_iters"], st["n_draft_calls"]))
+        d.close(); t.close()
+    assert res[0][:4] == res[1][:4]
+    assert res[0][4] < res[1][4]                              # one draft call per round instead of n_draft

@@ -85,6 +85,21 @@ def test_mul_mat_ragged_and_fused_residual(ea, gpu, tname):
         assert rel(gpu_mul_mat(ea, gpu, t, w, x, k, rows, residual=res), want + res) < 2e-5, (rows, k, T)
 
 
+def test_argmax_first_maximum(ea, gpu):
+    """GGML_OP_ARGMAX (greedy draft / verify steps fetch one int per token): first index of the row maximum, like ggml_vec_argmax_f32"""
+    rng = np.random.default_rng(12)
+    for ne0, rows in [(32000, 6), (100, 3), (1, 2), (4099, 1)]:
+        x = rng.standard_normal((rows, ne0)).astype(np.float32)
+        if ne0 > 50:
+            x[0, 7] = x[0, 41] = 9.0          # tie: the first one wins
+            x[-1, ne0 - 1] = 11.0             # maximum in the last element
+        g = ea.Graph(gpu)
+        a = g.tensor(ea.F32, ne0, rows); r = g.argmax(a)
+        g.alloc(); g.set(a, x); g.compute()
+        got = g.get(r, np.int32)
+        assert np.array_equal(got, np.argmax(x, axis=1).astype(np.int32)), (ne0, rows)
+
+
 def test_activation_edge_cases(ea, gpu):
     """all-zero activations, a zero super-block, +-max ties: quantised image must follow the CPU rule"""
     rng = np.random.default_rng(8)
