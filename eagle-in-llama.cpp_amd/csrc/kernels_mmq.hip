@@ -34,6 +34,24 @@ __device__ __forceinline__ i32x4 mfma_i8(const i32x4 a, const i32x4 b) {
     const i32x4 z = {0, 0, 0, 0};
     return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, z, 0, 0, 0);
 }
+// 16 bytes from an address that is only 2-byte aligned (Q6_K blocks are 210 bytes).  In this kernel's lane layout (16 rows x 64 B
+// per wave instruction) loads that are not dword-aligned run at about half rate (scripts/probe_unaligned.hip: 3.1 vs 5.6 TB/s;
+// scripts/probe_pattern.hip: the Q6_K pattern alone 21 us -> 13 us for ffn_down), so a fragment is kept as five aligned dwords
+// (the fifth only read when needed -- it never leaves the 210-byte block) and funnel-shifted by 0 or 16 bits at its first use.
+struct raw16 { i32x4 v; int e; };
+__device__ __forceinline__ raw16 ld16_a2(const char * p) {
+    const int mis = (int)((uintptr_t) p & 2);
+    const char * q = p - mis;                                  // pointer arithmetic, not an integer round trip: keeps the global address space
+    raw16 r; r.v = ld16(q); r.e = 0;
+    if (mis) __builtin_memcpy(&r.e, q + 16, 4);
+    return r;
+}
+__device__ __forceinline__ i32x4 fix16(const raw16 & r, int sh) {
+    i32x4 o;
+    o.x = __builtin_amdgcn_alignbit(r.v.y, r.v.x, sh); o.y = __builtin_amdgcn_alignbit(r.v.z, r.v.y, sh);
+    o.z = __builtin_amdgcn_alignbit(r.v.w, r.v.z, sh); o.w = __builtin_amdgcn_alignbit(r.e, r.v.w, sh);
+    return o;
+}
 __device__ __forceinline__ int byte_of(uint32_t v, int j) { return (int)((v >> (8*j)) & 0xffu); }
 __device__ __forceinline__ int sbyte_of(uint32_t v, int j) { return (int)(int8_t)((v >> (8*j)) & 0xffu); }
 
@@ -55,13 +73,15 @@ template <> struct mq_frag<GGML_TYPE_Q5_K> {
         qs[0] = ld16(b + 48 + 64*(kq >> 1) + 16*(kq & 1)); qs[1] = ld16(b + 48 + 64*(kq >> 1) + 32 + 16*(kq & 1));
     }
 };
-template <> struct mq_frag<GGML_TYPE_Q6_K> {          // kq = 2*qb + lh: ql bytes [64*nn + 32*qb + 16*lh, +16), qh bytes [32*nn + 16*lh, +16), nn = 0, 1
-    static constexpr int BLK = 210;
-    i32x4 ql[2], qh[2], sc; int dh;
+template <> struct mq_frag<GGML_TYPE_Q6_K> {          // kq = 2*qb + lh: ql bytes [64*nn + 32*qb + 16*lh, +16) for nn = 0, 1; qh bytes [16*kq, +16):
+    static constexpr int BLK = 210;                    // every byte of the block is requested once (the lanes swap qh pieces in registers)
+    raw16 ql[2], qh, sc; int dh, sh;
     __device__ __forceinline__ void load(const char * b, int kq) {
+        sh = (int)((uintptr_t) b & 2) * 8;             // all pieces sit at multiples of 16 from the block start: one shift for the fragment
 #pragma unroll
-        for (int nn = 0; nn < 2; ++nn) { ql[nn] = ld16(b + 64*nn + 32*(kq >> 1) + 16*(kq & 1)); qh[nn] = ld16(b + 128 + 32*nn + 16*(kq & 1)); }
-        sc = ld16(b + 192);
+        for (int nn = 0; nn < 2; ++nn) ql[nn] = ld16_a2(b + 64*nn + 32*(kq >> 1) + 16*(kq & 1));
+        qh = ld16_a2(b + 128 + 16*kq);
+        sc = ld16_a2(b + 192);
         uint16_t d; __builtin_memcpy(&d, b + 208, 2); dh = d;
     }
 };
@@ -146,14 +166,21 @@ template <int TG> struct mq_proc<GGML_TYPE_Q6_K, TG> { static __device__ __force
 #pragma unroll
         for (int r = 0; r < 4; ++r) isum[t][r] = 0;
     const int cls = g >> 1;
+    const i32x4 qh_own = fix16(f.qh, f.sh), scv = fix16(f.sc, f.sh);
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
-        const i32x4 hq = f.qh[nn] >> (2*qb);                               // bits 2q.. for q = qb (nib 0) at bit 0, for q = qb + 2 (nib 1) at bit 4
+        // this lane needs qh bytes [32nn + 16lh, +16): they were loaded by lane group kq' = 2nn + lh of the same row
+        const int src = 4*((lane & 15) + 16*(2*nn + lh));
+        i32x4 qhn;
+        qhn.x = __builtin_amdgcn_ds_bpermute(src, qh_own.x); qhn.y = __builtin_amdgcn_ds_bpermute(src, qh_own.y);
+        qhn.z = __builtin_amdgcn_ds_bpermute(src, qh_own.z); qhn.w = __builtin_amdgcn_ds_bpermute(src, qh_own.w);
+        const i32x4 hq = qhn >> (2*qb);                                    // bits 2q.. for q = qb (nib 0) at bit 0, for q = qb + 2 (nib 1) at bit 4
+        const i32x4 qln = fix16(f.ql[nn], f.sh);
 #pragma unroll
         for (int nib = 0; nib < 2; ++nib) {
-            const i32x4 b = nib ? (((f.ql[nn] >> 4) & 0x0F0F0F0F) | (hq & 0x30303030)) : ((f.ql[nn] & 0x0F0F0F0F) | ((hq << 4) & 0x30303030));
+            const i32x4 b = nib ? (((qln >> 4) & 0x0F0F0F0F) | (hq & 0x30303030)) : ((qln & 0x0F0F0F0F) | ((hq << 4) & 0x30303030));
             // scales[8nn + 4nib + 2p + lh]: the class of a C lane is lh -> shift once, then bytes 0 / 2 are passes p = 0 / 1
-            const uint32_t sw = (uint32_t) f.sc[2*nn + nib] >> (8*cls);
+            const uint32_t sw = (uint32_t) scv[2*nn + nib] >> (8*cls);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 const int q = p + 2*nib;
@@ -170,7 +197,7 @@ template <int TG> struct mq_proc<GGML_TYPE_Q6_K, TG> { static __device__ __force
         __builtin_amdgcn_sched_barrier(0);                                  // keep the two halves apart: bounds the live A / B operands
     }
     // -32 offset: 32 * sum_j scale_j * bsum16_j (class 0 = l parts, class 1 = h parts of the split sums)
-    const i32x4 bm = kq == 0 ? f.sc : (i32x4)(0);
+    const i32x4 bm = kq == 0 ? scv : (i32x4)(0);
     const float dw = h2f((uint16_t) f.dh);
     const int mscale = (g >> 1) ? 128*32 : 32;
 #pragma unroll
