@@ -102,8 +102,7 @@ void Backend::free_buffer(ggml_backend_buffer_t b) {
 Ctx::~Ctx() { for (auto b : buffers) be->free_buffer(b); }
 
 ggml_tensor * Ctx::new_tensor(int type, int64_t ne0, int64_t ne1, int64_t ne2, int64_t ne3, const char * name) {
-    pool.emplace_back();
-    ggml_tensor * t = &pool.back();
+    ggml_tensor * t = pool.push();
     memset(t, 0, sizeof(*t));
     auto tr = traits(type);
     t->type = (enum ggml_type) type;

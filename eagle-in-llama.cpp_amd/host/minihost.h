@@ -12,6 +12,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <deque>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -66,7 +67,18 @@ struct HostVec {
 // Tensor arena + op list + device memory for one graph (or for a set of persistent tensors).
 struct Ctx {
     Backend * be;
-    std::deque<ggml_tensor> pool;
+    // tensor arena: chunks of 256 structs that survive reset_graph() (a per-step graph is ~1000 tensors: no malloc per tensor, no
+    // re-faulting of the pages on every decode); pointers stay valid until the Ctx dies
+    struct TensorPool {
+        static constexpr size_t CHUNK = 256;
+        std::vector<std::unique_ptr<ggml_tensor[]>> chunks; size_t n = 0;
+        ggml_tensor * push() { if (n == chunks.size() * CHUNK) chunks.emplace_back(new ggml_tensor[CHUNK]); ggml_tensor * t = &chunks[n / CHUNK][n % CHUNK]; ++n; return t; }
+        void clear() { n = 0; }
+        size_t size() const { return n; }
+        ggml_tensor & operator[](size_t i) { return chunks[i / CHUNK][i % CHUNK]; }
+        struct iterator { TensorPool * p; size_t i; ggml_tensor & operator*() { return (*p)[i]; } iterator & operator++() { ++i; return *this; } bool operator!=(const iterator & o) const { return i != o.i; } };
+        iterator begin() { return { this, 0 }; } iterator end() { return { this, n }; }
+    } pool;
     std::vector<ggml_tensor *> nodes;            // ops in creation order == execution order
     std::vector<ggml_backend_buffer_t> buffers;  // owned
     std::vector<ggml_tensor **> node_ptrs_storage;
