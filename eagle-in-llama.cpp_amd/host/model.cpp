@@ -301,6 +301,24 @@ Model * Model::create_synthetic(mh::Backend * be, const ModelConfig & cfg, const
     return m;
 }
 
+// fp16 -> fp32 row conversion of the host-resident token embeddings (llama_set_inputs does the same through ggml_get_rows on the CPU
+// backend): F16C when the host has it (exact, so identical to the scalar routine), scalar otherwise
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("f16c,avx"))) static void h2f_row_f16c(const uint16_t * src, float * dst, int n) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) _mm256_storeu_ps(dst + i, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(src + i))));
+    for (; i < n; ++i) dst[i] = h2f(src[i]);
+}
+#endif
+static void h2f_row(const uint16_t * src, float * dst, int n) {
+#if defined(__x86_64__)
+    static const bool fast = __builtin_cpu_supports("f16c") && __builtin_cpu_supports("avx");
+    if (fast) { h2f_row_f16c(src, dst, n); return; }
+#endif
+    for (int i = 0; i < n; ++i) dst[i] = h2f(src[i]);
+}
+
 // ------------------------------------------------------------------ graph of one forward pass (build_llama :1647 / build_eagle :1839)
 void Model::build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<Cut> * cuts,
                           ggml_tensor *& result_norm, ggml_tensor *& result_output, ggml_tensor *& result_argmax) {
@@ -440,7 +458,7 @@ int Model::decode(const Batch & b, bool want_hidden) {
     auto flush = [&](ggml_tensor * t, char * h) { if (!packed) g.set(t, h, 0, mh::nbytes(t)); };
     {
         float * embd = (float *) host_of(inp_embd);
-        for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; float * dst = embd + (size_t) i * E; for (int j = 0; j < E; ++j) dst[j] = h2f(src[j]); }
+        for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; h2f_row(src, embd + (size_t) i * E, E); }
         flush(inp_embd, (char *) embd);
     }
     if (inp_hidd) { char * h = host_of(inp_hidd); memcpy(h, b.hidd.data(), (size_t) T * E * 4); flush(inp_hidd, h); }
@@ -448,7 +466,7 @@ int Model::decode(const Batch & b, bool want_hidden) {
     { char * h = host_of(inp_out); memcpy(h, out_ids.data(), (size_t) n_outputs * 4); flush(inp_out, h); }
     {
         float * mask = (float *) host_of(kq_mask);
-        std::fill(mask, mask + (size_t) n_kv * Tpad, -INFINITY);
+        std::fill(mask, mask + (size_t) n_kv * T, -INFINITY);        // rows T..Tpad-1 are padding no kernel reads (R pads for flash-attn only)
         for (int j = 0; j < T; ++j) {
             const uint64_t sbit = 1ull << b.seq_first[j]; const int32_t pos = b.pos[j];
             float * row = mask + (size_t) j * n_kv;
@@ -586,14 +604,14 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
         const Batch & b = bs[j]; const int T = in[j].T;
         if (in[j].embd) {
             float * embd = (float *) host_of(in[j].embd);
-            for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; float * dst = embd + (size_t) i * E; for (int q = 0; q < E; ++q) dst[q] = h2f(src[q]); }
+            for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; h2f_row(src, embd + (size_t) i * E, E); }
             flush(in[j].embd, (char *) embd);
             char * h = host_of(in[j].hidd); memcpy(h, b.hidd.data(), (size_t) T * E * 4); flush(in[j].hidd, h);
         }
         { char * h = host_of(in[j].pos); memcpy(h, b.pos.data(), (size_t) T * 4); flush(in[j].pos, h); }
         { int32_t last = T - 1; char * h = host_of(in[j].out); memcpy(h, &last, 4); flush(in[j].out, h); }
         float * mask = (float *) host_of(in[j].mask);
-        std::fill(mask, mask + (size_t) n_kv * in[j].Tpad, -INFINITY);
+        std::fill(mask, mask + (size_t) n_kv * T, -INFINITY);
         for (int r = 0; r < T; ++r) {
             const uint64_t sbit = 1ull << b.seq_first[r]; const int32_t pos = b.pos[r];
             float * row = mask + (size_t) r * n_kv;
