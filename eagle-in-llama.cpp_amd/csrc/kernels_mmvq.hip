@@ -347,7 +347,48 @@ __global__ void __launch_bounds__(NW*WAVE) k_quant_act(const act_src a, int k, c
         quant_q8K_to_lds<T, NW>(a, sc, k, q, d, bs, blockIdx.x*NW + wave, gridDim.x*NW, rec + (size_t) t0*nblk*32, rec + (size_t) Ttot*nblk*32 + (size_t) t0*nblk*32);
     } else quant_q80_to_lds<T, NW>(a, sc, k, q, d, blockIdx.x*NW + wave, gridDim.x*NW);
 }
+// K-quant images, one wave per (token, super-block): with a folded RMS norm the wave sums the squares of ITS token row itself
+// (16 KB at k = 4096, all loads in flight at once) and keeps the four values of its own super-block from that pass, so there is a
+// single memory phase, no block barrier, and T*k/256 waves run in parallel (k_quant_act: every block first reduces all T rows).
+__global__ void __launch_bounds__(512) k_quant_q8K(const act_src a, int k, char * out, int Ttot, int t0, int T) {
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    const int nsb = k/256, nu = T*nsb;
+    int8_t * q = (int8_t *) out + (size_t) t0*k;
+    float  * d = (float *)(out + (size_t) Ttot*k) + (size_t) t0*nsb;
+    short  * bs = (short *)(out + (size_t) Ttot*k + (size_t) Ttot*nsb*4) + (size_t) t0*(k/16);
+    char * rec = out + act_img_bytes(true, Ttot, k);
+    char * rec32 = rec + (size_t) t0*nsb*32, * rec16 = rec + (size_t) Ttot*nsb*32 + (size_t) t0*nsb*32;
+    for (int u = blockIdx.x*8 + wave; u < nu; u += gridDim.x*8) {
+        const int t = u / nsb, sb = u - t*nsb;
+        const float * row = a.X + (size_t) t*a.xs;
+        float4 v;
+        if (a.norm) {
+            double s = 0.0; v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int it0 = 0; it0*256 < k; it0 += 8) {               // 8 independent 16-byte loads per lane before the first use
+                float4 x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int i = (it0 + j)*256 + lane*4; x[j] = i < k ? *(const float4 *)(row + i) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s += (double)(x[j].x*x[j].x); s += (double)(x[j].y*x[j].y); s += (double)(x[j].z*x[j].z); s += (double)(x[j].w*x[j].w);
+                    if (it0 + j == sb) v = x[j];
+                }
+            }
+            const double tot = wave_sum_d(s);
+            const float mean = (float)(tot / (double) k), sc = 1.0f / sqrtf(mean + a.eps);
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            if (a.norm_w) { const float4 w = *(const float4 *)(a.norm_w + sb*256 + lane*4); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+        } else {
+            v = *(const float4 *)(row + sb*256 + lane*4);
+        }
+        quant_q8K_unit(v, lane, t, sb, k, nsb, q, d, bs, rec32, rec16);
+    }
+}
 template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src & a, int k, char * out, int Ttot, int t0) {
+    if (KQ) {
+        static const bool legacy = getenv("GGML_MI355X_QUANT_LEGACY") != nullptr;
+        if (!legacy) { const int nu = T * (k/256); int grid = (nu + 7) / 8; if (grid > 512) grid = 512; k_quant_q8K<<<grid, 512, 0, st>>>(a, k, out, Ttot, t0, T); return; }
+    }
     const int units = T * ((k + 255) / 256);
     int grid = (units + 8*2 - 1) / (8*2); if (grid > 64) grid = 64; if (grid < 1) grid = 1;
     switch (T) {

@@ -264,6 +264,20 @@ void mi_op_get_rows(hipStream_t st, const ggml_tensor * dst) {
 __global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, int32_t * __restrict__ dst, int64_t ne0, int64_t nb1) {
     const float * row = (const float *)(x + (int64_t) blockIdx.x * nb1);
     float best = -INFINITY; int bi = 0x7fffffff;
+    if ((ne0 & 3) == 0 && (((uintptr_t) row) & 15) == 0) {      // 16-byte loads, four of them in flight per lane (a 32000-entry logits row: two rounds)
+        const int64_t n4 = ne0 / 4;
+        for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 4*1024) {
+            float4 x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int64_t i = i0 + j*1024; x[j] = i < n4 ? ((const float4 *) row)[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = (int)((i0 + j*1024) * 4); const float xv[4] = { x[j].x, x[j].y, x[j].z, x[j].w };
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (xv[c] > best || (xv[c] == best && e + c < bi)) { best = xv[c]; bi = e + c; }
+            }
+        }
+    } else
     for (int64_t i = threadIdx.x; i < ne0; i += 1024) { const float v = row[i]; if (v > best || (v == best && (int) i < bi)) { best = v; bi = (int) i; } }
     if (bi == 0x7fffffff) bi = 0;                          // all NaN / -inf lanes fall back to index 0 like the CPU loop
     __shared__ float sv[16]; __shared__ int si[16];

@@ -99,6 +99,35 @@ __device__ __forceinline__ float4 fetch4(const act_src & a, const float * sc, in
 // Q8_K rule: the scale comes from the FIRST element of largest magnitude, iscale = -127/max,
 // q = min(127, rne(iscale*x)), d = 1/iscale, bsums over groups of 16.  One wave = one 256-element super-block;
 // loads for PB super-blocks are issued before the first reduction so their latencies overlap.
+// one 256-element super-block held by a wave (4 consecutive elements per lane) -> image of token t, super-block sb
+__device__ __forceinline__ void quant_q8K_unit(const float4 v4, int lane, int t, int sb, int k, int nsb, int8_t * q, float * d, short * bs, char * rec32, char * rec16) {
+    const float xv[4] = { v4.x, v4.y, v4.z, v4.w };
+    float amax = 0.0f; int first = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float ax = fabsf(xv[j]); if (ax > amax) { amax = ax; first = j; } }
+    const float wmax = wave_max_f(amax);
+    const int key = wave_min_i((amax == wmax) ? (lane*4 + first) : (1 << 20));     // lowest index holding the maximum
+    const float cand = (first == 0) ? xv[0] : (first == 1) ? xv[1] : (first == 2) ? xv[2] : xv[3];
+    const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand), (key >> 2) & 63));
+    int packed = 0; int s = 0; float dd = 0.0f;
+    if (wmax != 0.0f) {
+        const float iscale = -127.f / mx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { int qi = __float2int_rn(iscale * xv[j]); qi = min(127, qi); s += qi; packed |= (qi & 0xff) << (8*j); }
+        dd = 1.0f / iscale;
+    }
+    *(int *)(q + (size_t) t*k + sb*256 + lane*4) = packed;
+    s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s);
+    if ((lane & 3) == 0) bs[t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
+    if (lane == 0) d[t*nsb + sb] = dd;
+    if (rec32) {                                                       // split sums for the matrix-core kernel
+        int8_t * r32 = (int8_t *) rec32 + (size_t)(t*nsb + sb)*32, * r16 = (int8_t *) rec16 + (size_t)(t*nsb + sb)*32;
+        if ((lane & 3) == 0) { r16[lane >> 2] = (int8_t)(s & 127); r16[16 + (lane >> 2)] = (int8_t)(s >> 7); }
+        const int s2 = s + dpp_i<DPP_HMIR>(s);                          // quads are uniform: the other quad of the 8 lanes
+        if ((lane & 7) == 0) { r32[lane >> 3] = (int8_t)(s2 & 127); r32[16 + (lane >> 3)] = (int8_t)(s2 >> 7); }
+        if ((lane & 7) == 4) { r32[8 + (lane >> 3)] = 0; r32[24 + (lane >> 3)] = 0; }
+    }
+}
 template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const act_src & a, const float * sc, int k, int8_t * q, float * d, short * bs, int ubeg, int ustr, char * rec32 = nullptr, char * rec16 = nullptr) {
     const int lane = threadIdx.x % WAVE;
     const int nsb = k / 256, nu = T*nsb;
@@ -112,32 +141,7 @@ template <int T, int NW> __device__ __forceinline__ void quant_q8K_to_lds(const 
             const int u = u0 + p*ustr;
             if (u >= nu) break;
             const int t = u / nsb, sb = u - t*nsb;
-            const float xv[4] = { vv[p].x, vv[p].y, vv[p].z, vv[p].w };
-            float amax = 0.0f; int first = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float ax = fabsf(xv[j]); if (ax > amax) { amax = ax; first = j; } }
-            const float wmax = wave_max_f(amax);
-            const int key = wave_min_i((amax == wmax) ? (lane*4 + first) : (1 << 20));     // lowest index holding the maximum
-            const float cand = (first == 0) ? xv[0] : (first == 1) ? xv[1] : (first == 2) ? xv[2] : xv[3];
-            const float mx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand), (key >> 2) & 63));
-            int packed = 0; int s = 0; float dd = 0.0f;
-            if (wmax != 0.0f) {
-                const float iscale = -127.f / mx;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { int qi = __float2int_rn(iscale * xv[j]); qi = min(127, qi); s += qi; packed |= (qi & 0xff) << (8*j); }
-                dd = 1.0f / iscale;
-            }
-            *(int *)(q + t*k + sb*256 + lane*4) = packed;
-            s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s);
-            if ((lane & 3) == 0) bs[t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
-            if (lane == 0) d[t*nsb + sb] = dd;
-            if (rec32) {                                                       // split sums for the matrix-core kernel
-                int8_t * r32 = (int8_t *) rec32 + (size_t)(t*nsb + sb)*32, * r16 = (int8_t *) rec16 + (size_t)(t*nsb + sb)*32;
-                if ((lane & 3) == 0) { r16[lane >> 2] = (int8_t)(s & 127); r16[16 + (lane >> 2)] = (int8_t)(s >> 7); }
-                const int s2 = s + dpp_i<DPP_HMIR>(s);                          // quads are uniform: the other quad of the 8 lanes
-                if ((lane & 7) == 0) { r32[lane >> 3] = (int8_t)(s2 & 127); r32[16 + (lane >> 3)] = (int8_t)(s2 >> 7); }
-                if ((lane & 7) == 4) { r32[8 + (lane >> 3)] = 0; r32[24 + (lane >> 3)] = 0; }
-            }
+            quant_q8K_unit(vv[p], lane, t, sb, k, nsb, q, d, bs, rec32, rec16);
         }
     }
 }
