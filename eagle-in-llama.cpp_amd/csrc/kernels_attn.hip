@@ -46,6 +46,19 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
     const char * vb = (const char *) a.v + (int64_t) hk * a.v_nb2;
     constexpr int NS = D / 32;                             // MFMA k-steps over the head dim
 
+    // phase 3 geometry, known up front: blockIdx.z takes TPB of the D/16 output tiles; the 4 waves split (tile, cell range)
+    const int tpb = (D/16) / gridDim.z;                    // 1, 2 or 4 tiles per block
+    const int wpt = 4 / tpb;                               // waves sharing one tile
+    const int tile = blockIdx.z * tpb + wave / wpt, part = wave % wpt;
+    const int dd0 = tile * 16;
+    constexpr int VU = 4;                                  // 32-cell chunks in flight
+    // the first V^T fragments do not depend on the soft-max: their loads go out now and land during phases 1 and 2
+    i32x4 vf0[VU];
+#pragma unroll
+    for (int u = 0; u < VU; ++u) {
+        const int i = part*32 + u*wpt*32 + 8*grp;
+        vf0[u] = (i < n_kv) ? *(const i32x4 *)(vb + (int64_t)(dd0 + col) * a.v_nb1 + (int64_t) i * 2) : (i32x4)(0);
+    }
     // ---- phase 1: scores[cell][t] = K[cell][:] . q[t][:]      (A = 16 cells x 32 dims, B = 32 dims x 16 tokens)
     f16x8 qf[NS];
 #pragma unroll
@@ -59,7 +72,7 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
             for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16) 0.f;
         }
     }
-    constexpr int CU = 2;                                  // cell tiles in flight per wave (CU*NS 16-byte loads per lane)
+    constexpr int CU = 4;                                  // cell tiles in flight per wave (CU*NS 16-byte loads per lane): n_kv <= 256 is one round trip
     for (int c0 = wave*16; c0 < n_kv; c0 += 4*16*CU) {
         i32x4 kf[CU][NS];
 #pragma unroll
@@ -68,13 +81,29 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
 #pragma unroll
             for (int s = 0; s < NS; ++s) kf[u][s] = (cell < n_kv) ? *(const i32x4 *)(kb + (int64_t) cell * a.k_nb1 + (32*s + 8*grp) * 2) : (i32x4)(0);
         }
+        // the mask values of the C elements this lane will own go out with the K loads (phase 2 then never touches global memory)
+        f32x4 mk[CU];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const int r0 = c0 + u*64 + 4*grp;
+            mk[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (a.mask && col < nt && r0 < n_kv) {
+                const char * mrow = (const char *) a.mask + (int64_t)(t0 + col) * a.mask_nb1;
+                if (a.mask_f16) { const __half2 * m = (const __half2 *)(mrow + (int64_t) r0 * 2); const float2 lo = __half22float2(m[0]), hi = __half22float2(m[1]); mk[u] = (f32x4){lo.x, lo.y, hi.x, hi.y}; }
+                else mk[u] = *(const f32x4 *)(mrow + (int64_t) r0 * 4);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < NS; ++s) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(kf[u][s]), qf[s], c, 0, 0, 0);
             const int r0 = c0 + u*64 + 4*grp;              // C: column (token) = lane&15, rows (cells) = 4*(lane>>4) + 0..3
-            if (col < nt && r0 < n_kv) *(f32x4 *)(sc + col*ldS + r0) = c;
+            if (col < nt && r0 < n_kv) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { c[r] = __fmul_rn(c[r], a.scale); if (a.mask) c[r] = __fadd_rn(c[r], mk[u][r]); }     // scale, then mask: the order of ggml's soft_max
+                *(f32x4 *)(sc + col*ldS + r0) = c;
+            }
         }
     }
     __syncthreads();
@@ -84,14 +113,8 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
         if (t < nt) {
             float * row = sc + t*ldS;
             _Float16 * prow = ph + t*ldP;
-            const float * m32 = a.mask_f16 ? nullptr : (const float *)((const char *) a.mask + (int64_t)(t0 + t) * a.mask_nb1);
-            const __half * m16 = a.mask_f16 ? (const __half *)((const char *) a.mask + (int64_t)(t0 + t) * a.mask_nb1) : nullptr;
             float mx = -INFINITY;
-            for (int i = sub; i < n_kv; i += 16) {
-                float v = __fmul_rn(row[i], a.scale);
-                if (a.mask) v = __fadd_rn(v, a.mask_f16 ? __half2float(m16[i]) : m32[i]);
-                row[i] = v; mx = fmaxf(mx, v);
-            }
+            for (int i = sub; i < n_kv; i += 16) mx = fmaxf(mx, row[i]);
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
             double sum = 0.0;
@@ -104,19 +127,14 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
     }
     __syncthreads();
     // ---- phase 3: out[t][dd] = sum_i V^T[dd][i] * p[t][i]      (A = 16 head dims x 32 cells, B = 32 cells x 16 tokens)
-    //      blockIdx.z takes TPB of the D/16 output tiles; the 4 waves split (tile, cell range) and reduce through LDS
-    const int tpb = (D/16) / gridDim.z;                    // 1, 2 or 4 tiles per block
-    const int wpt = 4 / tpb;                               // waves sharing one tile
-    const int tile = blockIdx.z * tpb + wave / wpt, part = wave % wpt;
-    const int dd0 = tile * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    constexpr int VU = 4;                                  // 32-cell chunks in flight
     for (int i0 = part*32; i0 < n_kv; i0 += wpt*32*VU) {
         i32x4 vf[VU];
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
             const int i = i0 + u*wpt*32 + 8*grp;
-            vf[u] = (i < n_kv) ? *(const i32x4 *)(vb + (int64_t)(dd0 + col) * a.v_nb1 + (int64_t) i * 2) : (i32x4)(0);
+            if (i0 == part*32) vf[u] = vf0[u];
+            else vf[u] = (i < n_kv) ? *(const i32x4 *)(vb + (int64_t)(dd0 + col) * a.v_nb1 + (int64_t) i * 2) : (i32x4)(0);
         }
 #pragma unroll
         for (int u = 0; u < VU; ++u) {
@@ -144,6 +162,7 @@ bool mi_attn_small_supported(const mi_attn_args & a) {
     if (a.H % a.H_kv) return false;
     if (((uintptr_t) a.k | (uintptr_t) a.v | (uintptr_t) a.k_nb1 | (uintptr_t) a.k_nb2 | (uintptr_t) a.v_nb1 | (uintptr_t) a.v_nb2) & 15) return false;
     if (((uintptr_t) a.q | (uintptr_t) a.q_nb1 | (uintptr_t) a.q_nb2) & 3) return false;
+    if (a.mask && (((uintptr_t) a.mask | (uintptr_t) a.mask_nb1) & (a.mask_f16 ? 7 : 15))) return false;     // 4 mask values per lane in one load
     return true;
 }
 
