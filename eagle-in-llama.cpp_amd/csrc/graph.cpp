@@ -138,10 +138,16 @@ static inline bool name_is_result(const ggml_tensor * t) { return strncmp(t->nam
 struct act_plan { act_src src; const ggml_tensor * rms = nullptr, * mul = nullptr; };
 static bool plan_act(const gctx & c, const ggml_tensor * x, int k, int n_members_using_x, int last_member, act_plan & p) {
     p = act_plan();
-    p.src.X = (const float *) x->data; p.src.xs = x->nb[1]/4; p.src.norm = 0; p.src.norm_w = nullptr; p.src.eps = 0;
+    p.src.X = (const float *) x->data; p.src.xs = x->nb[1]/4; p.src.norm = 0; p.src.norm_w = nullptr; p.src.eps = 0; p.src.X2 = nullptr; p.src.xs2 = 0; p.src.ksplit = 0;
     const ggml_tensor * rms = nullptr, * mul = nullptr, * w = nullptr;
     if (x->op == GGML_OP_MUL && x->src[0] && x->src[0]->op == GGML_OP_RMS_NORM) { mul = x; rms = x->src[0]; w = x->src[1]; }
     else if (x->op == GGML_OP_RMS_NORM) rms = x;
+    if (x->op == GGML_OP_CONCAT && c.idx(x) >= 0 && c.done[c.idx(x)] == 2) {      // deferred by the CONCAT visit: read both halves in place
+        const ggml_tensor * a = x->src[0], * b = x->src[1];
+        p.src.X = (const float *) a->data; p.src.xs = a->nb[1]/4;
+        p.src.X2 = (const float *) b->data; p.src.xs2 = b->nb[1]/4; p.src.ksplit = (int) a->ne[0];
+        return true;
+    }
     if (!rms) return true;
     const int ir = c.idx(rms), im = mul ? c.idx(mul) : -1;
     if (ir < 0 || c.done[ir] != 2) return true;                       // 2 = deferred by the RMS_NORM visit below
@@ -191,11 +197,26 @@ static bool can_defer_norm(const gctx & c, int i) {
     return true;
 }
 
+// CONCAT(a, b) along dim 0 at node i feeding exactly one quantised mat-vec at node i+1 (EAGLE's fc over [embd; hidd]): the quantiser
+// reads the two halves in place.  Nothing runs between the two nodes, so a and b are still intact when the mat-vec starts.
+static bool can_defer_concat(const gctx & c, int i) {
+    const ggml_tensor * x = c.g->nodes[i];
+    if (mi_op_i32(x, 0) != 0 || c.n_uses(x) != 1 || (x->flags & GGML_TENSOR_FLAG_OUTPUT) || i + 1 >= c.n) return false;
+    const ggml_tensor * a = x->src[0], * b = x->src[1];
+    if (!is_f32(a) || !is_f32(b) || a->nb[0] != 4 || b->nb[0] != 4 || a->ne[1] != b->ne[1] || a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1) return false;
+    if ((a->ne[0] % 4) || (a->nb[1] % 16) || (b->nb[1] % 16) || ((uintptr_t) a->data % 16) || ((uintptr_t) b->data % 16)) return false;
+    const ggml_tensor * t = c.g->nodes[i + 1];
+    if (t->op != GGML_OP_MUL_MAT || t->src[1] != x || !mi_mul_mat_q_supported_type(t->src[0]->type) || t->src[0]->ne[2] != 1 || t->src[0]->ne[3] != 1) return false;
+    if (x->ne[2] != 1 || x->ne[3] != 1 || !mi_supports_op(0, t)) return false;
+    return true;
+}
+
 // ---- one member of a multi-matrix mat-vec launch and the nodes its epilogue swallows
 struct member {
     int node = -1; const ggml_tensor * mm = nullptr;
     int epi = EPI_F32; const ggml_tensor * out = nullptr;            // tensor that receives the result
-    const ggml_tensor * res = nullptr;                                // residual for EPI_F32
+    const ggml_tensor * res = nullptr;                                // residual (or broadcast bias row) for EPI_F32
+    bool relu = false;                                                // EPI_F32: fused UNARY(RELU)
     const ggml_tensor * rope = nullptr;
     std::vector<int> swallowed;                                       // node indices done by this member
 };
@@ -210,7 +231,7 @@ static bool rope_fusable(const ggml_tensor * r, const ggml_tensor * mm) {
 // follow mm's result: [RESHAPE] -> ROPE -> (CPY to f16 cache)?  |  [TRANSPOSE] -> CPY f16  |  ADD residual  |  plain
 static void plan_member(const gctx & c, member & m) {
     const ggml_tensor * mm = m.mm;
-    m.epi = EPI_F32; m.out = mm; m.res = nullptr; m.rope = nullptr; m.swallowed.clear();
+    m.epi = EPI_F32; m.out = mm; m.res = nullptr; m.relu = false; m.rope = nullptr; m.swallowed.clear();
     if ((mm->flags & GGML_TENSOR_FLAG_OUTPUT) || c.n_uses(mm) != 1) return;
     const ggml_tensor * c1 = c.g->nodes[c.last_use(mm)];
     // optional reshape
@@ -239,18 +260,27 @@ static void plan_member(const gctx & c, member & m) {
             return;
         }
     }
-    // residual: the very next node adds a same-shaped f32 tensor
+    // residual: the very next node adds a same-shaped f32 tensor -- or a bias row broadcast over the tokens (EAGLE's fc.bias)
+    const ggml_tensor * tail = mm;
     if (c1->op == GGML_OP_ADD && c.idx(c1) == m.node + 1 && is_f32(c1) && c1->nb[0] == 4 && mi_same_shape(c1, mm)) {
         const ggml_tensor * other = c1->src[0] == mm ? c1->src[1] : c1->src[0];
-        if (other != mm && is_f32(other) && mi_same_shape(other, mm) && other->nb[0] == 4) { m.res = other; m.out = c1; m.swallowed.push_back(c.idx(c1)); }
+        const bool bias = other != mm && c1->src[0] == mm && is_f32(other) && other->nb[0] == 4 && other->ne[0] == mm->ne[0] && mi_nrows(other) == 1;
+        if (other != mm && is_f32(other) && other->nb[0] == 4 && (mi_same_shape(other, mm) || bias)) { m.res = other; m.out = c1; m.swallowed.push_back(c.idx(c1)); tail = c1; }
+    }
+    // RELU right behind (fc -> +bias -> relu)
+    if (c.n_uses(tail) == 1 && !(tail->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+        const ggml_tensor * u = c.g->nodes[c.last_use(tail)];
+        if (u->op == GGML_OP_UNARY && mi_op_i32(u, 0) == GGML_UNARY_OP_RELU && u->src[0] == tail && c.idx(u) == c.idx(tail) + 1 && is_f32(u) && mi_is_contiguous(u) && mi_same_shape(u, mm) && u->nb[0] == 4) {
+            m.relu = true; m.out = u; m.swallowed.push_back(c.idx(u));
+        }
     }
 }
 static void fill_mat(mmvq_mat & M, const member & m) {
     const ggml_tensor * w = m.mm->src[0];
-    M.W = (const char *) w->data; M.row_bytes = w->nb[1]; M.rows = (int) w->ne[1]; M.epi = m.epi; M.res = nullptr; M.r_tok = 0;
+    M.W = (const char *) w->data; M.row_bytes = w->nb[1]; M.rows = (int) w->ne[1]; M.epi = m.epi; M.res = nullptr; M.r_tok = 0; M.relu = m.relu ? 1 : 0;
     M.out = (char *) m.out->data;
     switch (m.epi) {
-        case EPI_F32:      M.o_row = 4; M.o_tok = m.out->nb[1]; if (m.res) { M.res = (const float *) m.res->data; M.r_tok = m.res->nb[1]/4; } break;
+        case EPI_F32:      M.o_row = 4; M.o_tok = m.out->nb[1]; if (m.res) { M.res = (const float *) m.res->data; M.r_tok = mi_nrows(m.res) == 1 ? 0 : m.res->nb[1]/4; } break;
         case EPI_ROPE_F32: M.o_row = 4; M.o_tok = (int64_t) w->ne[1] * 4; break;                         // rope out is contiguous [d, heads, T]
         case EPI_ROPE_F16: M.o_row = 2; M.o_tok = (int64_t) w->ne[1] * 2; break;                         // contiguous f16 slice
         case EPI_F16:      M.o_row = m.out->nb[1]; M.o_tok = 2; break;                                   // out [T, rows]: token fastest
@@ -331,12 +361,20 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
             const size_t nb = mi_nbytes(m.out);
             static const bool dbg = getenv("GGML_MI355X_DEBUG_GROUP") != nullptr;
             if (write_conflicts(c, m.out->data, nb, i, orig, sk)) { if (dbg) MI_LOG("group at %s: member %s not hoisted (write conflict, epi %d, out %s)", t->name, m.mm->name, m.epi, m.out->name); continue; }   // leave it to run at its own position
-            if (overlap(m.out->data, nb, ap.src.X, (size_t) T * ap.src.xs * 4)) { if (dbg) MI_LOG("group at %s: member %s not hoisted (overlaps activations)", t->name, m.mm->name); continue; }
+            if (overlap(m.out->data, nb, ap.src.X, (size_t) T * ap.src.xs * 4) || (ap.src.X2 && overlap(m.out->data, nb, ap.src.X2, (size_t) T * ap.src.xs2 * 4))) { if (dbg) MI_LOG("group at %s: member %s not hoisted (overlaps activations)", t->name, m.mm->name); continue; }
         }
         skip[m.node] = 1; for (int s : m.swallowed) skip[s] = 1;
         sel[keep++] = m;
     }
     if (keep == 0) return false;
+    if (ap.src.X2) {       // deferred CONCAT: ggml-alloc may have handed the memory of its sources to one of our outputs -- then build it after all
+        bool clash = false;
+        for (int q = 0; q < keep; ++q) {
+            const size_t nb = mi_nbytes(sel[q].out);
+            if (overlap(sel[q].out->data, nb, ap.src.X, (size_t) T * ap.src.xs * 4) || overlap(sel[q].out->data, nb, ap.src.X2, (size_t) T * ap.src.xs2 * 4)) clash = true;
+        }
+        if (clash) { mi_op_concat(st, x); ap.src.X = (const float *) x->data; ap.src.xs = x->nb[1]/4; ap.src.X2 = nullptr; ap.src.xs2 = 0; ap.src.ksplit = 0; }
+    }
     { static const bool dbg = getenv("GGML_MI355X_DEBUG_GROUP") != nullptr; if (dbg) MI_LOG("group at %s: %d siblings, %d kept, T=%d", t->name, nm, keep, T); }
     mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = keep; L.swiglu = 0;
     for (int q = 0; q < keep; ++q) fill_mat(L.m[q], sel[q]);
@@ -437,7 +475,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
             case GGML_OP_SCALE:    mi_op_scale(st, t); break;
             case GGML_OP_CPY:      mi_op_cpy(st, t->src[0], t->src[1]); break;
             case GGML_OP_CONT: case GGML_OP_DUP: mi_op_cpy(st, t->src[0], t); break;
-            case GGML_OP_CONCAT:   mi_op_concat(st, t); break;
+            case GGML_OP_CONCAT:   if (fuse && can_defer_concat(c, i)) { c.done[i] = 2; break; } mi_op_concat(st, t); break;
             case GGML_OP_GET_ROWS: mi_op_get_rows(st, t); break;
             case GGML_OP_ARGMAX:   mi_op_argmax(st, t); break;
             case GGML_OP_ROPE:     mi_op_rope(st, t); break;

@@ -23,11 +23,13 @@ enum { EPI_F32 = 0, EPI_ROPE_F32 = 1, EPI_ROPE_F16 = 2, EPI_F16 = 3 };
 struct act_src {                        // activations of a mat-vec launch (see kernels_mmvq.hip)
     const float * X; int64_t xs; const float * norm_w; int norm; float eps;
     const char * pre;                  // non-NULL: activations already quantised by mi_quant_act (image in HBM scratch)
+    const float * X2; int64_t xs2; int ksplit;   // X2 non-NULL: the activations are CONCAT(X, X2) along k, X2 starting at element ksplit (EAGLE's [embd; hidd])
 };
 struct mmvq_mat {
     const char * W; int64_t row_bytes; int rows; int epi;
     char * out; int64_t o_row, o_tok;   // element (row, token) is written at out + row*o_row + token*o_tok  (bytes)
-    const float * res; int64_t r_tok;   // optional residual (EPI_F32): res[token*r_tok + row]
+    const float * res; int64_t r_tok;   // optional residual (EPI_F32): res[token*r_tok + row]; r_tok = 0 broadcasts a bias row
+    int relu;                           // EPI_F32: max(x, 0) after the residual / bias (fused GGML_UNARY_OP_RELU)
 };
 struct mmvq_rope { const int32_t * pos; int head_dim; float theta_scale, freq_scale, attn_factor; };
 struct mmvq_launch { act_src act; int k; int n_mat; int swiglu; mmvq_mat m[3]; mmvq_rope rope; };

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
                 for (int r = 0; r < 4; ++r) { const int tok = 4*tg + r; if (in && tok < T) { const float g0 = v[0][r]; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = (g0 / (1.0f + expf(-g0))) * v[NM - 1][r]; } }
             } else if (M.epi == EPI_F32) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const int tok = 4*tg + r; if (in && tok < T) { float o = v[0][r]; if (M.res) o += M.res[(size_t) tok*M.r_tok + row]; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = o; } }
+                for (int r = 0; r < 4; ++r) { const int tok = 4*tg + r; if (in && tok < T) { float o = v[0][r]; if (M.res) o += M.res[(size_t) tok*M.r_tok + row]; if (M.relu) o = o > 0.f ? o : 0.f; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = o; } }
             } else if (M.epi == EPI_F16) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int tok = 4*tg + r; if (in && tok < T) *(__half *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = __float2half_rn(v[0][r]); }

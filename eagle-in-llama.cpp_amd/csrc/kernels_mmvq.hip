@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmvq(const mmvq_launch L) {
             for (int t = 0; t < T; ++t) if (lane == t) {
                 float v0 = acc[0][t], v1 = acc[NF > 1 ? 1 : 0][t];
                 if (M.res) { v0 += M.res[(size_t) t*M.r_tok + cur_row0]; if (ok1) v1 += M.res[(size_t) t*M.r_tok + cur_row0 + 1]; }
+                if (M.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
                 *(float *)(M.out + (size_t) cur_row0*M.o_row + (size_t) t*M.o_tok) = v0;
                 if (ok1) *(float *)(M.out + (size_t)(cur_row0 + 1)*M.o_row + (size_t) t*M.o_tok) = v1;
             }
@@ -379,7 +380,8 @@ __global__ void __launch_bounds__(512) k_quant_q8K(const act_src a, int k, char 
             v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
             if (a.norm_w) { const float4 w = *(const float4 *)(a.norm_w + sb*256 + lane*4); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
         } else {
-            v = *(const float4 *)(row + sb*256 + lane*4);
+            const int e = sb*256 + lane*4;
+            v = (a.X2 && e >= a.ksplit) ? *(const float4 *)(a.X2 + (size_t) t*a.xs2 + (e - a.ksplit)) : *(const float4 *)(row + e);
         }
         quant_q8K_unit(v, lane, t, sb, k, nsb, q, d, bs, rec32, rec16);
     }

@@ -88,7 +88,7 @@ template <int T, int NW> __device__ __forceinline__ void row_scales(const act_sr
     __syncthreads();
 }
 __device__ __forceinline__ float4 fetch4(const act_src & a, const float * sc, int t, int e) {
-    float4 v = *(const float4 *)(a.X + t*a.xs + e);
+    float4 v = (a.X2 && e >= a.ksplit) ? *(const float4 *)(a.X2 + t*a.xs2 + (e - a.ksplit)) : *(const float4 *)(a.X + t*a.xs + e);
     if (a.norm) {
         const float s = sc[t];
         v.x *= s; v.y *= s; v.z *= s; v.w *= s;
