@@ -194,6 +194,24 @@ def test_small_ops_vs_reference_backend(ea, gpu, ref_cpu):
     got, want = _both(ea, gpu, ref_cpu, b7, [tab, idx]); assert np.array_equal(got, want)
 
 
+def test_eagle_fc_front_fused_vs_reference_backend(ea, gpu, ref_cpu):
+    """CONCAT([embd; hidd]) -> MUL_MAT(fc) -> ADD(bias row) -> RELU (R/src/llama.cpp:1863-1869) runs as ONE launch on the GPU
+    (two-source quantiser, broadcast bias, relu epilogue); same graph on the reference CPU backend.  T = 1 takes the dp4a kernel
+    with its in-block quantiser, T = 6 the quantise-once image + matrix-core kernel."""
+    rng = np.random.default_rng(21)
+    for t, T in [(12, 1), (12, 6), (14, 3), (8, 2)]:
+        E = 1024
+        w = qdata.random_blocks(t, E, 2 * E, rng)
+        e = rng.standard_normal((T, E)).astype(np.float32); hdn = rng.standard_normal((T, E)).astype(np.float32)
+        bias = rng.standard_normal(E).astype(np.float32) * 20
+        def build(g):
+            a = g.tensor(ea.F32, E, T); b = g.tensor(ea.F32, E, T); wt = g.tensor(t, 2 * E, E); bb = g.tensor(ea.F32, E)
+            return [a, b, wt, bb], g.unary(g.add(g.mul_mat(wt, g.concat(a, b, 0)), bb), "relu")
+        got, want = _both(ea, gpu, ref_cpu, build, [e, hdn, w, bias])
+        assert rel(got, want) < 2e-5, (t, T)
+        assert (got >= 0).all() and (got == 0).any() and (got > 0).any()
+
+
 def test_attention_subgraph_tree_mask(ea, gpu):
     """K.q -> soft_max(tree mask) -> V.p -> permute -> cont, on the fp16 KV layout of the reference"""
     z = np.load(os.path.join(GOLD, "small_ops.npz"))
