@@ -22,6 +22,29 @@ static inline bool is_view_op(int op) {
 }
 static inline bool is_f32(const ggml_tensor * t) { return t && t->type == GGML_TYPE_F32; }
 
+// FLASH_ATTN_EXT(q f32 [d, T, H], k f16 [d, n_kv, H_kv], v f16 [d, n_kv, H_kv], mask f16 [n_kv, pad(T)]) -> f32 [d, H, T]
+// (ggml_flash_attn_ext, R/ggml/src/ggml.c; CPU twin ggml_compute_forward_flash_attn_ext_f16): the fused attention kernel with a
+// row-major V.  No ALiBi, no logit soft-cap, f16 cache only -- everything else is declined and stays on the CPU.
+bool mi_flash_attn_args(const ggml_tensor * op, mi_attn_args & a) {
+    const ggml_tensor * q = op->src[0], * k = op->src[1], * v = op->src[2], * mask = op->src[3];
+    if (!q || !k || !v || !is_f32(q) || !is_f32(op) || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16) return false;
+    if (mi_op_f32(op, 1) != 0.0f || mi_op_f32(op, 2) != 0.0f) return false;                    // max_bias, logit_softcap
+    if (q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1 || q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2) return false;
+    if (k->ne[0] != q->ne[0] || v->ne[0] != q->ne[0] || v->ne[1] != k->ne[1] || v->ne[2] != k->ne[2]) return false;
+    if (mask && !(mask->type == GGML_TYPE_F16 && mi_is_contiguous(mask) && mask->ne[0] == k->ne[1] && mask->ne[1] >= q->ne[1] && mask->ne[2] == 1 && mask->ne[3] == 1)) return false;
+    if (!mi_is_contiguous(op) || op->ne[0] != v->ne[0] || op->ne[1] != q->ne[2] || op->ne[2] != q->ne[1]) return false;
+    a = mi_attn_args{};
+    a.d = (int) q->ne[0]; a.T = (int) q->ne[1]; a.H = (int) q->ne[2]; a.n_kv = (int) k->ne[1]; a.H_kv = (int) k->ne[2];
+    a.q = q->data; a.q_nb1 = q->nb[1]; a.q_nb2 = q->nb[2];
+    a.k = k->data; a.k_nb1 = k->nb[1]; a.k_nb2 = k->nb[2];
+    a.v = v->data; a.v_nb1 = v->nb[1]; a.v_nb2 = v->nb[2]; a.v_row = 1;
+    a.mask = mask ? mask->data : nullptr; a.mask_f16 = 1; a.mask_nb1 = mask ? mask->nb[1] : 0;
+    a.out = (float *) op->data; a.o_nb1 = (int64_t) a.d * 4; a.o_nb2 = (int64_t) a.d * a.H * 4;
+    a.scale = mi_op_f32(op, 0);
+    // supports_op is also asked before buffers exist (data == NULL): alignment of the base pointers is checked again at run time
+    return mi_attn_small_supported(a);
+}
+
 bool mi_supports_op(int, const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0], * b = op->src[1];
     switch (op->op) {
@@ -62,6 +85,10 @@ bool mi_supports_op(int, const ggml_tensor * op) {
             return is_f32(a) && is_f32(b) && is_f32(op);
         case GGML_OP_GET_ROWS:
             return (a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16) && b->type == GGML_TYPE_I32 && is_f32(op);
+        case GGML_OP_FLASH_ATTN_EXT: {
+            mi_attn_args fa;
+            return mi_flash_attn_args(op, fa);
+        }
         case GGML_OP_ARGMAX:
             return is_f32(a) && a->nb[0] == 4 && a->ne[2] == 1 && a->ne[3] == 1 && op->type == GGML_TYPE_I32 && mi_is_contiguous(op) && a->ne[0] < (1ll << 31);
         case GGML_OP_ROPE: {
@@ -478,6 +505,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
             case GGML_OP_CONCAT:   if (fuse && can_defer_concat(c, i)) { c.done[i] = 2; break; } mi_op_concat(st, t); break;
             case GGML_OP_GET_ROWS: mi_op_get_rows(st, t); break;
             case GGML_OP_ARGMAX:   mi_op_argmax(st, t); break;
+            case GGML_OP_FLASH_ATTN_EXT: { mi_attn_args fa; if (!mi_flash_attn_args(t, fa)) { MI_LOG("flash_attn_ext: operands changed since supports_op"); return GGML_STATUS_FAILED; } mi_op_attn_small(st, fa); } break;
             case GGML_OP_ROPE:     mi_op_rope(st, t); break;
             case GGML_OP_SOFT_MAX: mi_op_soft_max(st, t); break;
             default:

@@ -59,7 +59,8 @@ bool mi_mul_mat_q_supported_type(int type);
 struct mi_attn_args {
     const void * q;      int64_t q_nb1, q_nb2;          // f32 [d, T, H]   (strides in bytes)
     const void * k;      int64_t k_nb1, k_nb2;          // f16 [d, n_kv, H_kv]
-    const void * v;      int64_t v_nb1, v_nb2;          // f16 [n_kv, d, H_kv]   (transposed V cache)
+    const void * v;      int64_t v_nb1, v_nb2;          // f16 [n_kv, d, H_kv] (transposed V cache: v_nb1 = stride of a head dim), or with
+    int v_row;                                          // v_row = 1 (FLASH_ATTN_EXT): f16 [d, n_kv, H_kv], v_nb1 = stride of a cache cell
     const void * mask;   int     mask_f16; int64_t mask_nb1;  // [n_kv, >=T]
     float      * out;    int64_t o_nb1, o_nb2;          // f32, element (dd, h, t) at dd*4 + h*o_nb1 + t*o_nb2
     int d, T, H, H_kv, n_kv;

@@ -28,7 +28,7 @@ __device__ __forceinline__ f16x8 as_h8(const i32x4 v) { return __builtin_bit_cas
 __device__ __forceinline__ float rnd16(float v) { return __half2float(__float2half_rn(v)); }
 
 // LDS image: sc [tt][n_kv + 4] fp32 scores, ph [tt][n_kv + 8] f16 probabilities, red [4][64] float4 partial tiles
-static inline size_t attn_lds_bytes(int n_kv, int tt) { return (size_t) tt * (n_kv + 4) * 4 + (size_t) tt * (n_kv + 8) * 2 + 4 * 64 * 16; }
+static inline size_t attn_lds_bytes(int n_kv, int tt) { return (size_t) tt * (n_kv + 4) * 4 + (size_t) tt * (n_kv + 8) * 2 + 4 * 64 * 16 + 4 * 4 * 1024; }    // + per-wave V staging (row-major V only)
 
 template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_attn_args a, const int tt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -37,6 +37,7 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
     float    * sc  = (float *) lds;
     _Float16 * ph  = (_Float16 *)(lds + (size_t) tt * ldS * 4);
     f32x4    * red = (f32x4 *)(lds + (size_t) tt * ldS * 4 + (size_t) tt * ldP * 2);
+    _Float16 * stg = (_Float16 *)((char *) red + 4*64*16);              // [4 waves][4 chunks][32 cells][16 head dims]: row-major V -> B operands
     const int h = blockIdx.x, t0 = blockIdx.y * tt;
     const int nt = min(tt, a.T - t0);
     const int hk = h / (a.H / a.H_kv);
@@ -57,7 +58,8 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
 #pragma unroll
     for (int u = 0; u < VU; ++u) {
         const int i = part*32 + u*wpt*32 + 8*grp;
-        vf0[u] = (i < n_kv) ? *(const i32x4 *)(vb + (int64_t)(dd0 + col) * a.v_nb1 + (int64_t) i * 2) : (i32x4)(0);
+        if (a.v_row) { const int cell = part*32 + u*wpt*32 + (lane >> 1); vf0[u] = (cell < n_kv) ? *(const i32x4 *)(vb + (int64_t) cell * a.v_nb1 + (int64_t)(dd0 + 8*(lane & 1)) * 2) : (i32x4)(0); }
+        else vf0[u] = (i < n_kv) ? *(const i32x4 *)(vb + (int64_t)(dd0 + col) * a.v_nb1 + (int64_t) i * 2) : (i32x4)(0);
     }
     // ---- phase 1: scores[cell][t] = K[cell][:] . q[t][:]      (A = 16 cells x 32 dims, B = 32 dims x 16 tokens)
     f16x8 qf[NS];
@@ -128,6 +130,7 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
     __syncthreads();
     // ---- phase 3: out[t][dd] = sum_i V^T[dd][i] * p[t][i]      (A = 16 head dims x 32 cells, B = 32 cells x 16 tokens)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (!a.v_row) {
     for (int i0 = part*32; i0 < n_kv; i0 += wpt*32*VU) {
         i32x4 vf[VU];
 #pragma unroll
@@ -143,14 +146,44 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(vf[u]), as_h8(pf), acc, 0, 0, 0);
         }
     }
+    } else {
+    // row-major V (FLASH_ATTN_EXT): out[t][dd] = sum_i p[t][i] * V[i][dd] with A = p (16 tokens x 32 cells) and B = V (32 cells x 16 head dims).
+    // A lane's B fragment is a COLUMN of V (8 cells of one head dim): the 32 x 16 chunk is fetched with one coalesced 16-byte load per lane
+    // (cell = lane/2, 8 head dims each), parked in a wave-private LDS tile, and read back as 8 halves.
+    _Float16 * my = stg + (size_t) wave * 4 * 512;
+    for (int i0 = part*32; i0 < n_kv; i0 += wpt*32*VU) {
+        i32x4 vr[VU];
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int cell = i0 + u*wpt*32 + (lane >> 1);
+            if (i0 == part*32) vr[u] = vf0[u];
+            else vr[u] = (cell < n_kv) ? *(const i32x4 *)(vb + (int64_t) cell * a.v_nb1 + (int64_t)(dd0 + 8*(lane & 1)) * 2) : (i32x4)(0);
+        }
+#pragma unroll
+        for (int u = 0; u < VU; ++u) *(i32x4 *)(my + u*512 + (lane >> 1)*16 + 8*(lane & 1)) = vr[u];
+#pragma unroll
+        for (int u = 0; u < VU; ++u) {
+            const int i = i0 + u*wpt*32 + 8*grp;
+            f16x8 bv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bv[j] = my[u*512 + (8*grp + j)*16 + col];
+            const i32x4 pf = (col < nt && i < n_kv) ? *(const i32x4 *)(ph + col*ldP + i) : (i32x4)(0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_h8(pf), bv, acc, 0, 0, 0);       // C: column = head dim lane&15, rows = tokens 4*(lane>>4) + 0..3
+        }
+    }
+    }
     if (wpt > 1) {
         if (part) red[wave*64 + lane] = acc;
         __syncthreads();
         if (part == 0) for (int w = 1; w < wpt; ++w) acc += red[(wave + w)*64 + lane];
     }
-    if (part == 0 && col < nt) {                           // C: column (token) = lane&15, rows (head dims) = 4*(lane>>4) + 0..3
+    if (part == 0 && !a.v_row && col < nt) {               // C: column (token) = lane&15, rows (head dims) = 4*(lane>>4) + 0..3
         float * o = (float *)((char *) a.out + (int64_t)(dd0 + 4*grp)*4 + (int64_t) h * a.o_nb1 + (int64_t)(t0 + col) * a.o_nb2);
         o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+    }
+    if (part == 0 && a.v_row) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int tok = 4*grp + r; if (tok < nt) *(float *)((char *) a.out + (int64_t)(dd0 + col)*4 + (int64_t) h * a.o_nb1 + (int64_t)(t0 + tok) * a.o_nb2) = acc[r]; }
     }
 }
 
