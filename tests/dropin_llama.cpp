@@ -113,6 +113,7 @@ static bool run(const std::string & tgt_path, const std::string & dft_path, cons
     llama_context_params cp = llama_context_default_params();
     cp.n_ctx = d.n_ctx; cp.n_batch = 64; cp.n_ubatch = 64; cp.n_seq_max = 4; cp.embeddings = true;    // the fork only yields logits with embeddings on
     cp.n_threads = 4; cp.n_threads_batch = 4;
+    cp.flash_attn = getenv("DROPIN_FLASH_ATTN") != nullptr;     // -fa: GGML_OP_FLASH_ATTN_EXT, row-major V cache, f16 mask, n_kv padded to 256
     g_trace = getenv("DROPIN_TRACE") != nullptr; g_cur = &o;
     if (g_trace) { cp.cb_eval = trace_cb; cp.cb_eval_user_data = nullptr; }
     llama_context * ct = llama_init_from_model(mt, cp);

@@ -13,11 +13,13 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "dropin_llama")
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/dropin_llama not built")]
 
 
-@pytest.mark.parametrize("fusion", ["fused", "unfused"])
+@pytest.mark.parametrize("fusion", ["fused", "unfused", "flash_attn"])
 def test_reference_llama_decode_on_plugin(ea, tmp_path, fusion):
     env = dict(os.environ)
     if fusion == "unfused":
         env["GGML_MI355X_NO_FUSION"] = "1"
+    if fusion == "flash_attn":                       # the reference's example commands use -fa: FLASH_ATTN_EXT runs on the plugin too
+        env["DROPIN_FLASH_ATTN"] = "1"
     out = subprocess.run([BIN, ea.require_plugin(), str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
     txt = out.stdout + out.stderr
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
