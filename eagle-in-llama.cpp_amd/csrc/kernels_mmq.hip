@@ -60,7 +60,7 @@ template <int TYPE> struct mq_frag;
 template <> struct mq_frag<GGML_TYPE_Q4_K> {          // qs bytes [32*gA + 16*(kq&1), +16) for gA = (kq>>1)*2 + {0, 1}
     static constexpr int BLK = 144;
     i32x4 hdr, qs[2];
-    __device__ __forceinline__ void load(const char * b, int kq) {
+    __device__ __forceinline__ void load(const char * b, int kq, int) {
         hdr = ld16(b);
         qs[0] = ld16(b + 16 + 64*(kq >> 1) + 16*(kq & 1)); qs[1] = ld16(b + 16 + 64*(kq >> 1) + 32 + 16*(kq & 1));
     }
@@ -68,7 +68,7 @@ template <> struct mq_frag<GGML_TYPE_Q4_K> {          // qs bytes [32*gA + 16*(k
 template <> struct mq_frag<GGML_TYPE_Q5_K> {
     static constexpr int BLK = 176;
     i32x4 hdr, qh, qs[2];
-    __device__ __forceinline__ void load(const char * b, int kq) {
+    __device__ __forceinline__ void load(const char * b, int kq, int) {
         hdr = ld16(b); qh = ld16(b + 16 + 16*(kq & 1));
         qs[0] = ld16(b + 48 + 64*(kq >> 1) + 16*(kq & 1)); qs[1] = ld16(b + 48 + 64*(kq >> 1) + 32 + 16*(kq & 1));
     }
@@ -76,7 +76,7 @@ template <> struct mq_frag<GGML_TYPE_Q5_K> {
 template <> struct mq_frag<GGML_TYPE_Q6_K> {          // kq = 2*qb + lh: ql bytes [64*nn + 32*qb + 16*lh, +16) for nn = 0, 1; qh bytes [16*kq, +16):
     static constexpr int BLK = 210;                    // every byte of the block is requested once (the lanes swap qh pieces in registers)
     raw16 ql[2], qh, sc; int dh, sh;
-    __device__ __forceinline__ void load(const char * b, int kq) {
+    __device__ __forceinline__ void load(const char * b, int kq, int) {
         sh = (int)((uintptr_t) b & 2) * 8;             // all pieces sit at multiples of 16 from the block start: one shift for the fragment
 #pragma unroll
         for (int nn = 0; nn < 2; ++nn) ql[nn] = ld16_a2(b + 64*nn + 32*(kq >> 1) + 16*(kq & 1));
@@ -86,8 +86,25 @@ template <> struct mq_frag<GGML_TYPE_Q6_K> {          // kq = 2*qb + lh: ql byte
     }
 };
 
+template <> struct mq_frag<GGML_TYPE_Q8_0> {          // a unit = 8 blocks of 34 bytes (f16 d + 32 int8); MFMA a covers blocks 2a (class 0) and 2a+1 (class 1):
+    static constexpr int BLK = 272;                    // lane kq holds the 16 quants [16*(kq&1), +16) of block 2a + (kq>>1); blocks are 2-byte aligned
+    raw16 q[4]; int dh[4]; int shs;
+    __device__ __forceinline__ void load(const char * b, int kq, int nb_left) {
+        shs = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int blk = 2*a + (kq >> 1);
+            const char * p = b + (blk < nb_left ? blk : 0)*34;            // past the ragged end: any valid block, its product meets zero activations
+            const char * qp = p + 2 + 16*(kq & 1);
+            shs |= (int)(((uintptr_t) qp & 2) >> 1) << a;
+            q[a] = ld16_a2(qp);
+            uint16_t d; __builtin_memcpy(&d, p, 2); dh[a] = d;
+        }
+    }
+};
+
 // LDS view of the activation image
-struct mq_act { const int8_t * q; int ldq; const float * d; const char * rec; int nsb; int T; };
+struct mq_act { const int8_t * q; int ldq; const float * d; const char * rec; int nsb; int T; };   // nsb: scales per token (super-blocks; 32-blocks for Q8_0)
 
 // ---- one super-block of 16 rows x T tokens.  The M dimension of the MFMA carries (token, class): M rows 0..7 are the
 // tokens against the k-slots of one sub-block, M rows 8..15 the same tokens against another sub-block, the activations
@@ -214,9 +231,35 @@ template <int TG> struct mq_proc<GGML_TYPE_Q6_K, TG> { static __device__ __force
     }
 } };
 
-static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual) {
-    const size_t nsb = k/256;
-    return (size_t) T*(k + 16) + (((size_t) T*nsb*4 + 15) & ~(size_t) 15) + (size_t) T*nsb*32 + (size_t) NW*64*16*(dual ? 2 : 1);      // the reduction tiles are re-used per token group
+template <int TG> struct mq_proc<GGML_TYPE_Q8_0, TG> { static __device__ __forceinline__ void run(const mq_frag<GGML_TYPE_Q8_0> & f, const mq_act & A, int unit, int lane, float (&acc)[TG][4]) {
+    // ggml_vec_dot_q8_0_q8_0: sumf += sumi * (d_x * d_y) per 32-element block; activations quantised with quantize_row_q8_0 (image d per block)
+    const int i = lane & 15, kq = lane >> 4, g = kq;
+    const int tok_a = i & 7, cls_a = i >> 3, cls = g >> 1;
+    const bool cv = cls_a == (kq >> 1);
+    const int nblk = A.nsb;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const i32x4 b = fix16(f.q[a], ((f.shs >> a) & 1) * 16);
+        const int blk_a = unit*8 + 2*a + cls_a, blk_c = unit*8 + 2*a + cls;       // block seen by this lane's A rows / owned by its C values
+        const float dw = h2f((uint16_t) f.dh[a]);
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            const bool av = cv && tok_a + 8*t < A.T && blk_a < nblk;
+            const i32x4 am = av ? *(const i32x4 *)(A.q + (tok_a + 8*t)*A.ldq + blk_a*32 + 16*(kq & 1)) : (i32x4)(0);
+            const i32x4 c = mfma_i8(am, b);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tok = 8*t + 4*(g & 1) + r;
+                const float dy = (tok < A.T && blk_c < nblk) ? A.d[tok*nblk + blk_c] : 0.f;
+                acc[t][r] += (float) c[r] * (dw*dy);
+            }
+        }
+    }
+} };
+
+static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual, bool q80 = false) {
+    const size_t nsc = q80 ? k/32 : k/256;                   // scales per token
+    return (size_t) T*(k + 16) + (((size_t) T*nsc*4 + 15) & ~(size_t) 15) + (q80 ? 0 : (size_t) T*nsc*32) + (size_t) NW*64*16*(dual ? 2 : 1);      // the reduction tiles are re-used per token group
 }
 
 // PF: double-buffer the weight fragments (the loads of unit u+1 fly while unit u is computed); without it a wave keeps one
@@ -224,11 +267,12 @@ static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual) {
 template <int TYPE, bool DUAL, int NW, bool PF, int TG>
 __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int k = L.k, nsb = k/256, ldq = k + 16;
+    constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0;
+    const int k = L.k, nsb = Q80 ? k/32 : k/256, nun = Q80 ? (k/32 + 7)/8 : k/256, ldq = k + 16;      // nsb: scales per token, nun: units per row
     int8_t * lq  = (int8_t *) smem;
     float  * ldy = (float *)(smem + (size_t) T*ldq);
     char   * lrec = (char *) ldy + (((size_t) T*nsb*4 + 15) & ~(size_t) 15);
-    f32x4  * red = (f32x4 *)(lrec + (size_t) T*nsb*32);
+    f32x4  * red = (f32x4 *)(lrec + (Q80 ? 0 : (size_t) T*nsb*32));
     const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
     const int kq = lane >> 4;
     constexpr int BLK = mq_frag<TYPE>::BLK;
@@ -238,7 +282,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
     const int c1 = (!DUAL && L.n_mat > 1) ? (L.m[1].rows + 15) / 16 : 0;
     const int c2 = (!DUAL && L.n_mat > 2) ? (L.m[2].rows + 15) / 16 : 0;
     const int total = c0 + c1 + c2;
-    const int nu = wave < nsb ? ((nsb - wave + NW - 1) / NW) * NM : 0;    // (matrix, super-block) units of this wave per row group
+    const int nu = wave < nun ? ((nun - wave + NW - 1) / NW) * NM : 0;    // (matrix, super-block) units of this wave per row group
 
     const char * rp[NM];
     auto set_rows = [&](int g, int & mi, int & row0) {
@@ -246,19 +290,22 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
         rp[0] = L.m[mi].W + (size_t) min(row0 + (lane & 15), L.m[mi].rows - 1) * L.m[mi].row_bytes;
         if (DUAL) rp[NM - 1] = L.m[1].W + (size_t) min(row0 + (lane & 15), L.m[1].rows - 1) * L.m[1].row_bytes;
     };
+    auto nb_left = [&](int u) -> int { const int unit = DUAL ? wave + (u >> 1)*NW : wave + u*NW; return Q80 ? k/32 - unit*8 : 8; };     // blocks of the row from this unit on (Q8_0: ragged last unit)
     auto unit_ptr = [&](int u) -> const char * { return DUAL ? rp[u & 1] + (size_t)(wave + (u >> 1)*NW) * BLK : rp[0] + (size_t)(wave + u*NW) * BLK; };
 
     mq_frag<TYPE> fa, fb;          // fb unused without PF
     int grp = blockIdx.x, mi = 0, row0 = 0;
-    if (grp < total) { set_rows(grp, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq); }      // in flight across the prologue
+    if (grp < total) { set_rows(grp, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq, nb_left(0)); }      // in flight across the prologue
     {   // activation image (HBM scratch, written by k_quant_act) -> LDS; token rows padded by 16 bytes against bank conflicts
         const int nthr = NW*WAVE, n16row = k/16;
         const i32x4 * src = (const i32x4 *) L.act.pre;
         for (int c = threadIdx.x; c < T*n16row; c += nthr) { const int t = c / n16row, o = c - t*n16row; *(i32x4 *)(lq + (size_t) t*ldq + o*16) = src[c]; }
         const float * sd = (const float *)(L.act.pre + (size_t) T*k);
         for (int c = threadIdx.x; c < T*nsb; c += nthr) ldy[c] = sd[c];
-        const char * sr = L.act.pre + act_img_bytes(true, T, k) + (TYPE == GGML_TYPE_Q6_K ? (size_t) T*nsb*32 : 0);     // 4-byte aligned only
-        for (int c = threadIdx.x; c < T*nsb*2; c += nthr) ((i32x4 *) lrec)[c] = ld16(sr + (size_t) c*16);
+        if (!Q80) {
+            const char * sr = L.act.pre + act_img_bytes(true, T, k) + (TYPE == GGML_TYPE_Q6_K ? (size_t) T*nsb*32 : 0);     // 4-byte aligned only
+            for (int c = threadIdx.x; c < T*nsb*2; c += nthr) ((i32x4 *) lrec)[c] = ld16(sr + (size_t) c*16);
+        }
     }
     __syncthreads();
     const mq_act A = { lq, ldq, ldy, lrec, nsb, T };
@@ -273,22 +320,22 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
                 for (int r = 0; r < 4; ++r) acc[m][t][r] = 0.f;
         if (PF) {
             for (int u = 0; u < nu; u += 2) {
-                if (u + 1 < nu) fb.load(unit_ptr(u + 1), kq);
+                if (u + 1 < nu) fb.load(unit_ptr(u + 1), kq, nb_left(u + 1));
                 mq_proc<TYPE, TG>::run(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[0]);                 // DUAL: even units = gate
                 if (u + 1 >= nu) break;
-                if (u + 2 < nu) fa.load(unit_ptr(u + 2), kq);
+                if (u + 2 < nu) fa.load(unit_ptr(u + 2), kq, nb_left(u + 2));
                 mq_proc<TYPE, TG>::run(fb, A, DUAL ? wave + ((u + 1) >> 1)*NW : wave + (u + 1)*NW, lane, acc[NM - 1]);   // DUAL: odd units = up
             }
         } else {
             for (int u = 0; u < nu; u += NM) {
                 mq_proc<TYPE, TG>::run(fa, A, DUAL ? wave + (u >> 1)*NW : wave + u*NW, lane, acc[0]);
-                if (DUAL) { fa.load(unit_ptr(u + 1), kq); mq_proc<TYPE, TG>::run(fa, A, wave + (u >> 1)*NW, lane, acc[NM - 1]); }
-                if (u + NM < nu) fa.load(unit_ptr(u + NM), kq);
+                if (DUAL) { fa.load(unit_ptr(u + 1), kq, nb_left(u + 1)); mq_proc<TYPE, TG>::run(fa, A, wave + (u >> 1)*NW, lane, acc[NM - 1]); }
+                if (u + NM < nu) fa.load(unit_ptr(u + NM), kq, nb_left(u + NM));
             }
         }
         // next group's first loads go out before this group's reduction / epilogue
         const int cmi = mi, crow0 = row0, gn = grp + gridDim.x;
-        if (gn < total) { set_rows(gn, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq); }
+        if (gn < total) { set_rows(gn, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq, nb_left(0)); }
         // ---- split-K reduction in a fixed order (wave 0 adds the partial tiles of waves 0..NW-1), one token group at a time
 #pragma unroll
         for (int tgi = 0; tgi < TG; ++tgi) {
@@ -360,7 +407,7 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
 }
 
 template <int TYPE, bool DUAL, int NW, bool PF, int TG> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
-    const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL);
+    const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL, TYPE == GGML_TYPE_Q8_0);
     MI_ASSERT(lds <= 160*1024 && L.act.pre);
     int total = 0;
     if (DUAL) total = (L.m[0].rows + 15) / 16;
@@ -377,7 +424,7 @@ template <int TYPE, bool DUAL, int NW, bool PF, int TG> static void mmq_launch_o
 template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmvq_launch & L) {
     int total = 0;
     for (int i = 0; i < (L.swiglu ? 1 : L.n_mat); ++i) total += (L.m[i].rows + 15) / 16;
-    constexpr bool PF = TYPE != GGML_TYPE_Q6_K;
+    constexpr bool PF = TYPE != GGML_TYPE_Q6_K && TYPE != GGML_TYPE_Q8_0;      // wide fragments: single-buffered to stay at 4 waves/SIMD
     if (T > 8) {      // several groups of 8 tokens per pass (prompt / large verification batches): weights and their unpacking are shared
         const int tg = (T + 7) / 8;
         // register budget: 3 groups (24 tokens) per pass, 2 for the dual gate|up kernel
@@ -387,15 +434,15 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
         return;
     }
     // few row groups and a long k: 16 waves per group so that every wave still has <= ~3 super-blocks in sequence
-    const bool wide = total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu) <= 160*1024;
+    const bool wide = TYPE != GGML_TYPE_Q8_0 && total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu, TYPE == GGML_TYPE_Q8_0) <= 160*1024;
     if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false, 1>(st, T, L); else mmq_launch_one<TYPE, true, 8, PF, 1>(st, T, L); }
     else          { if (wide) mmq_launch_one<TYPE, false, 16, PF, 1>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF, 1>(st, T, L); }
 }
 
 bool mi_mmq_supported(int type, int T, int k, bool swiglu) {
-    if (!(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K)) return false;
-    if (T < 1 || T > (swiglu ? 16 : 24) || k % 256) return false;
-    return mmq_lds_bytes(T, k, 8, true) <= 158*1024;
+    if (!(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K || type == GGML_TYPE_Q8_0)) return false;
+    if (T < 1 || T > (swiglu ? 16 : 24) || k % (type == GGML_TYPE_Q8_0 ? 32 : 256)) return false;
+    return mmq_lds_bytes(T, k, 8, true, type == GGML_TYPE_Q8_0) <= 158*1024;
 }
 // most tokens one pass can take: a multiple of 8 (whole token groups) once above 8
 int mi_mmq_max_tokens(int type, int k, bool swiglu) {
@@ -409,6 +456,7 @@ void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L) {
         case GGML_TYPE_Q4_K: mmq_launch_type<GGML_TYPE_Q4_K>(st, T, L); break;
         case GGML_TYPE_Q5_K: mmq_launch_type<GGML_TYPE_Q5_K>(st, T, L); break;
         case GGML_TYPE_Q6_K: mmq_launch_type<GGML_TYPE_Q6_K>(st, T, L); break;
+        case GGML_TYPE_Q8_0: mmq_launch_type<GGML_TYPE_Q8_0>(st, T, L); break;
         default: MI_ABORT("mmq: unsupported weight type %d", type);
     }
 }

@@ -28,6 +28,7 @@
 #include <unordered_map>
 #include <unordered_set>
 #include <cstdlib>
+#include <cstdio>
 #include <vector>
 
 #include "mmvq_device.h"
@@ -574,6 +575,7 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
             }
             L.act.pre = cache->pool + (size_t) hit * cache->slot_bytes;
         }
+        { static const bool dbg = getenv("GGML_MI355X_DEBUG_MMQ") != nullptr; if (dbg) fprintf(stderr, "[mi355x] mat-vec type %d T %d (of %d, tmax %d) k %d -> %s\n", type, T, Ttot, tmax, L.k, mmq ? "mmq" : "mmvq"); }
         if (mmq) { mi_mmq_launch(st, type, T, L); continue; }
         switch (type) {
             case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, T, L); break;

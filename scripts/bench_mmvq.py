@@ -47,6 +47,10 @@ def run(t, rows, k, T, mode, nrep=None):
         if best is None or gbs > best[0]: best = (gbs, out[0] * 1e3 / n, n)
     print("%-5s rows %6d k %6d T %d %-7s launches %3d avg %7.2f us  %7.1f GB/s (%4.1f%% of 8 TB/s)" % (NAMES[t], rows, k, T, mode, best[2], best[1], best[0], best[0] / 80), flush=True)
 shapes = [(4096, 4096), (11008, 4096), (4096, 11008), (32000, 4096)]
+if len(sys.argv) > 1 and sys.argv[1] == "q8":          # Q8_0 shapes (config 3), T = 1 / 6 / 24
+    for T in (1, 6, 24):
+        for rows, k in ((4096, 4096), (11008, 4096), (4096, 11008)): run(8, rows, k, T, "plain")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "single":      # the model's single-matrix launches (wo, ffn_down, lm_head) at T = 6
     for t in (12, 14):
         for rows, k in ((4096, 4096), (4096, 11008), (32000, 4096)): run(t, rows, k, 6, "single")
