@@ -25,6 +25,12 @@ def _run_all(ea, be, config, ftype):
     h = ea._model_sigs()
     h.eh_model_kv_seq_cp(m.h, 0, 1, -1, -1); h.eh_model_kv_seq_cp(m.h, 0, 2, -1, -1)
     lgt, hidt = m.decode([10, 11, 12, 13, 14], [17, 18, 17, 18, 19], seq=[1, 1, 2, 2, 2]); res += [lgt, hidt]
+    # wide tree verification (BASELINE config 3: width 10, depth 6): ten branches hanging off the common prefix, 60 tokens in one
+    # batch -> several 24-token passes of the matrix-core mat-vec, attention tiles of 16 tokens, ten-way tree mask
+    m.kv_seq_rm(-1, 17, -1)
+    for s_ in range(3, 13): h.eh_model_kv_seq_cp(m.h, 0, s_, -1, -1)
+    wt = [100 + 7 * i for i in range(60)]; wp = [17 + (i % 6) for i in range(60)]; ws = [3 + i // 6 for i in range(60)]
+    lgw, hidw = m.decode(wt, wp, seq=ws); res += [lgw, hidw]
     # EAGLE head: features in, logits through the target's LM head
     lgd, hidd = d.decode([30, 31, 32], [1, 2, 3], hidd=hid[:3]); res += [lgd, hidd]
     lgd2, _ = d.decode([33], [4], hidd=hidd[2:3]); res += [lgd2]
