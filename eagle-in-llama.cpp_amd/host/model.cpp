@@ -405,6 +405,7 @@ int Model::decode(const Batch & b, bool want_hidden) {
     const int T = b.n_tokens();
     if (T <= 0) return -1;
     if (cfg.eagle && (int) b.hidd.size() != T * cfg.n_embd) return -2;
+    for (int i = 0; i < T; ++i) if (b.token[i] < 0 || b.token[i] >= cfg.n_vocab) return -6;       // llama_decode: "invalid token" (R/src/llama.cpp:9500)
     if (!kv.find_slot(b)) return 1;
     const uint32_t pad = 32;                                 // llama_kv_cache_get_padding without flash-attn
     kv.n = std::min(kv.size, std::max(pad, (kv.cell_max() + pad - 1) / pad * pad));
@@ -530,6 +531,7 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     const int T0 = first.n_tokens(), E = cfg.n_embd;
     if (!cfg.eagle || cfg.tp_size > 1 || T0 <= 0 || n_steps < 1) return -1;
     if ((int) first.hidd.size() != T0 * E) return -2;
+    for (int i = 0; i < T0; ++i) if (first.token[i] < 0 || first.token[i] >= cfg.n_vocab) return -6;
     if (!tok_embd_dev) {                                       // the reference keeps token_embd on the host; the fused loop needs it next to the arg-max
         ectx.reset(new mh::Ctx(be)); ectx->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
         tok_embd_dev = ectx->new_tensor(GGML_TYPE_F16, E, cfg.n_vocab, 1, 1, "token_embd.weight");

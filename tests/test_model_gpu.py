@@ -29,7 +29,7 @@ def _run_all(ea, be, config, ftype):
     # batch -> several 24-token passes of the matrix-core mat-vec, attention tiles of 16 tokens, ten-way tree mask
     m.kv_seq_rm(-1, 17, -1)
     for s_ in range(3, 13): h.eh_model_kv_seq_cp(m.h, 0, s_, -1, -1)
-    wt = [100 + 7 * i for i in range(60)]; wp = [17 + (i % 6) for i in range(60)]; ws = [3 + i // 6 for i in range(60)]
+    wt = [(100 + 7 * i) % 512 for i in range(60)]; wp = [17 + (i % 6) for i in range(60)]; ws = [3 + i // 6 for i in range(60)]
     lgw, hidw = m.decode(wt, wp, seq=ws); res += [lgw, hidw]
     # EAGLE head: features in, logits through the target's LM head
     lgd, hidd = d.decode([30, 31, 32], [1, 2, 3], hidd=hid[:3]); res += [lgd, hidd]
