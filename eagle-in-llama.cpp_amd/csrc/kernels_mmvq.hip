@@ -403,6 +403,12 @@ template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src 
 }
 size_t mi_act_image_bytes(int type, int T, int k) { return (act_img_bytes_full(mi_traits(type).blck == 256, T, k) + 255) & ~(size_t) 255; }
 void mi_quant_act(hipStream_t st, int type, int T, const act_src & a0, int k, char * out) {
+    static const bool legacy = getenv("GGML_MI355X_QUANT_LEGACY") != nullptr;
+    if (mi_traits(type).blck == 256 && !legacy) {             // one wave per (token, super-block): any number of tokens in one launch
+        const int nu = T * (k/256); int grid = (nu + 7) / 8; if (grid > 1024) grid = 1024;
+        k_quant_q8K<<<grid, 512, 0, st>>>(a0, k, out, T, 0, T);
+        return;
+    }
     for (int t0 = 0; t0 < T; t0 += 8) {                       // images of more than 8 tokens (matrix-core kernel) are filled 8 tokens per launch
         act_src a = a0; a.X += (size_t) t0 * a.xs;
         const int n = T - t0 < 8 ? T - t0 : 8;
