@@ -435,7 +435,7 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
     }
     // few row groups and a long k: 16 waves per group so that every wave still has <= ~3 super-blocks in sequence
     const bool wide = TYPE != GGML_TYPE_Q8_0 && total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu, TYPE == GGML_TYPE_Q8_0) <= 160*1024;
-    if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false, 1>(st, T, L); else mmq_launch_one<TYPE, true, 8, PF, 1>(st, T, L); }
+    if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false, 1>(st, T, L); else mmq_launch_one<TYPE, true, 8, false, 1>(st, T, L); }      // gate|up: single-buffered fragments fit two blocks per CU (21.0 -> 18.8 us)
     else          { if (wide) mmq_launch_one<TYPE, false, 16, PF, 1>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF, 1>(st, T, L); }
 }
 
