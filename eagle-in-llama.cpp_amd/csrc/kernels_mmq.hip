@@ -406,6 +406,9 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
     return g_occ[fn];
 }
 
+// tuning knob (experiments only): GGML_MI355X_MMQ_CFG bit 0 = single-buffered fragments everywhere, bit 1 = never 16-wave blocks, bit 2 = one block per row group
+static int mmq_cfg() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMQ_CFG"); return e ? atoi(e) : 0; }(); return v; }
+
 template <int TYPE, bool DUAL, int NW, bool PF, int TG> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
     const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL, TYPE == GGML_TYPE_Q8_0);
     MI_ASSERT(lds <= 160*1024 && L.act.pre);
@@ -416,12 +419,14 @@ template <int TYPE, bool DUAL, int NW, bool PF, int TG> static void mmq_launch_o
     auto fn = k_mmq<TYPE, DUAL, NW, PF, TG>;
     int per_cu = blocks_per_cu((const void *) fn, NW*WAVE, lds);
     if (per_cu > 4) per_cu = 4;
-    const int grid = total < 256*per_cu ? total : 256*per_cu;
+    int grid = total < 256*per_cu ? total : 256*per_cu;
+    if (mmq_cfg() & 4) grid = total;                                      // experiment: no persistent cap
     const int pi = mi_prof_begin(st, L, T, DUAL);
     fn<<<grid, NW*WAVE, lds, st>>>(L, T);
     mi_prof_end(st, pi);
 }
 template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmvq_launch & L) {
+    const int cfg = mmq_cfg();
     int total = 0;
     for (int i = 0; i < (L.swiglu ? 1 : L.n_mat); ++i) total += (L.m[i].rows + 15) / 16;
     constexpr bool PF = TYPE != GGML_TYPE_Q6_K && TYPE != GGML_TYPE_Q8_0;      // wide fragments: single-buffered to stay at 4 waves/SIMD
@@ -434,9 +439,9 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
         return;
     }
     // few row groups and a long k: 16 waves per group so that every wave still has <= ~3 super-blocks in sequence
-    const bool wide = TYPE != GGML_TYPE_Q8_0 && total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu, TYPE == GGML_TYPE_Q8_0) <= 160*1024;
+    const bool wide = !(cfg & 2) && TYPE != GGML_TYPE_Q8_0 && total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu, TYPE == GGML_TYPE_Q8_0) <= 160*1024;
     if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false, 1>(st, T, L); else mmq_launch_one<TYPE, true, 8, false, 1>(st, T, L); }      // gate|up: single-buffered fragments fit two blocks per CU (21.0 -> 18.8 us)
-    else          { if (wide) mmq_launch_one<TYPE, false, 16, PF, 1>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF, 1>(st, T, L); }
+    else          { if (wide) mmq_launch_one<TYPE, false, 16, PF, 1>(st, T, L); else if (cfg & 1) mmq_launch_one<TYPE, false, 8, false, 1>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF, 1>(st, T, L); }
 }
 
 bool mi_mmq_supported(int type, int T, int k, bool swiglu) {
