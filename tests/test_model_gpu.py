@@ -117,3 +117,17 @@ def test_fused_draft_chain_equals_stepwise(ea, gpu, monkeypatch):
         d.close(); t.close()
     assert res[0][:4] == res[1][:4]
     assert res[0][4] < res[1][4]                              # one draft call per round instead of n_draft
+
+
+@pytest.mark.gpu
+def test_long_generation_stays_lossless(ea, gpu):
+    """1500 generated tokens on the tiny pair: n_kv grows through many 32-cell paddings (attention LDS image sizes, 8- and
+    16-token tiles, the fused draft chain's up-front KV slots); speculative output must stay identical to plain greedy decoding."""
+    t = ea.Model(gpu, "tiny-gqa", "q4_k_m", n_ctx=2048, seed=21)
+    d = ea.Model(gpu, "tiny-gqa", "q4_k_m", n_ctx=2048, eagle_of=t, seed=21, accept_p=0.8)
+    prompt = [int(x) for x in np.random.default_rng(5).integers(5, 512, 40)]
+    plain, _ = ea.plain_generate(t, prompt, 1500)
+    spec, st = ea.spec_generate(t, d, prompt, 1500, n_draft=5)
+    assert plain == spec[:len(plain)]
+    assert st["n_accept"] > 100
+    d.close(); t.close()
