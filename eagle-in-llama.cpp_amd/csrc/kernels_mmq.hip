@@ -1,4 +1,4 @@
-// kernels_mmq.hip -- K-quant weight x int8 activation products for 1..8 tokens on the matrix cores.
+// kernels_mmq.hip -- quantised weight (Q4_K, Q5_K, Q6_K, Q8_0) x int8 activation products for 2..24 tokens per pass on the matrix cores.
 //
 // Same arithmetic as kernels_mmvq.hip (the CPU backend's: Q8_K activations, the integer dot products of
 // ggml_vec_dot_{q4_K,q5_K,q6_K}_q8_K, R/ggml/src/ggml-cpu/ggml-cpu-quants.c), different machine mapping: the dp4a
@@ -17,7 +17,10 @@
 //     groups g = 0, 1, lanes kq>=2 groups 2, 3 -> 4 MFMAs per super-block.
 //   * Q6_K: 16-element sub-blocks: a B operand holds four of them; two MFMAs with complementary activation masks read it.
 //   * mins (Q4_K/Q5_K) and the -32 offset (Q6_K) are sum_j m_j * bsum_j: one more MFMA against the block sums, which
-//     k_quant_act stores split as 128*h + l (both int8; l = class 0, h = class 1).
+//     the quantiser stores split as 128*h + l (both int8; l = class 0, h = class 1).
+//   * Q8_0: two 32-element blocks per MFMA (one per class), fp32 scale d_w * d_a per (row, token, block) as in
+//     ggml_vec_dot_q8_0_q8_0.
+//   * TG groups of 8 tokens per pass (prompt / wide verification batches): the unpacked B operand meets TG activation operands.
 // A 512/1024-thread block owns 16 rows; its waves split the super-blocks of the row (split-K) and reduce through LDS in
 // a fixed order.  The quantised activation image (mi_quant_act) is copied into LDS once per block.
 #include <hip/hip_runtime.h>
@@ -263,7 +266,7 @@ static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual, bool q80 = f
 }
 
 // PF: double-buffer the weight fragments (the loads of unit u+1 fly while unit u is computed); without it a wave keeps one
-// fragment set and relies on the other waves of its SIMD to cover the load latency (Q6_K: the register budget for 4 waves/SIMD)
+// fragment set and relies on the other waves of its SIMD to cover the load latency (Q6_K, Q8_0, gate|up: the register budget for 4 waves/SIMD)
 template <int TYPE, bool DUAL, int NW, bool PF, int TG>
 __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
