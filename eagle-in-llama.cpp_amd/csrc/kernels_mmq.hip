@@ -106,6 +106,22 @@ template <> struct mq_frag<GGML_TYPE_Q8_0> {          // a unit = 8 blocks of 34
     }
 };
 
+template <> struct mq_frag<GGML_TYPE_Q4_0> {          // a unit = 8 blocks of 18 bytes (f16 d + 16 bytes of nibbles: low = elements 0..15, high = 16..31);
+    static constexpr int BLK = 144;                    // MFMA a covers blocks 2a (class 0) and 2a+1 (class 1); lane kq takes the low (kq&1 = 0) or high nibbles
+    raw16 q[4]; int dh[4]; int shs;
+    __device__ __forceinline__ void load(const char * b, int kq, int nb_left) {
+        shs = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int blk = 2*a + (kq >> 1);
+            const char * p = b + (blk < nb_left ? blk : 0)*18;
+            shs |= (int)(((uintptr_t)(p + 2) & 2) >> 1) << a;
+            q[a] = ld16_a2(p + 2);
+            uint16_t d; __builtin_memcpy(&d, p, 2); dh[a] = d;
+        }
+    }
+};
+
 // LDS view of the activation image
 struct mq_act { const int8_t * q; int ldq; const float * d; const char * rec; int nsb; int T; };   // nsb: scales per token (super-blocks; 32-blocks for Q8_0)
 
@@ -260,6 +276,35 @@ template <int TG> struct mq_proc<GGML_TYPE_Q8_0, TG> { static __device__ __force
     }
 } };
 
+template <int TG> struct mq_proc<GGML_TYPE_Q4_0, TG> { static __device__ __forceinline__ void run(const mq_frag<GGML_TYPE_Q4_0> & f, const mq_act & A, int unit, int lane, float (&acc)[TG][4]) {
+    // ggml_vec_dot_q4_0_q8_0: sumi = sum (q - 8) * a per 32-element block, sumf += (sumi * d_x) * d_y.  sum q*a and sum a come from two
+    // MFMAs against the same activation operand (the second one with an all-ones B), so no block sums are needed in the image.
+    const int i = lane & 15, kq = lane >> 4, g = kq;
+    const int tok_a = i & 7, cls_a = i >> 3, cls = g >> 1;
+    const bool cv = cls_a == (kq >> 1);
+    const int nblk = A.nsb;
+    const i32x4 ones = (i32x4)(0x01010101);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const i32x4 raw = fix16(f.q[a], ((f.shs >> a) & 1) * 16);
+        const i32x4 b = (kq & 1) ? ((raw >> 4) & 0x0F0F0F0F) : (raw & 0x0F0F0F0F);
+        const int blk_a = unit*8 + 2*a + cls_a, blk_c = unit*8 + 2*a + cls;
+        const float dw = h2f((uint16_t) f.dh[a]);
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            const bool av = cv && tok_a + 8*t < A.T && blk_a < nblk;
+            const i32x4 am = av ? *(const i32x4 *)(A.q + (tok_a + 8*t)*A.ldq + blk_a*32 + 16*(kq & 1)) : (i32x4)(0);
+            const i32x4 c = mfma_i8(am, b), sa = mfma_i8(am, ones);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tok = 8*t + 4*(g & 1) + r;
+                const float dy = (tok < A.T && blk_c < nblk) ? A.d[tok*nblk + blk_c] : 0.f;
+                acc[t][r] += ((float)(c[r] - 8*sa[r]) * dw) * dy;
+            }
+        }
+    }
+} };
+
 static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual, bool q80 = false) {
     const size_t nsc = q80 ? k/32 : k/256;                   // scales per token
     return (size_t) T*(k + 16) + (((size_t) T*nsc*4 + 15) & ~(size_t) 15) + (q80 ? 0 : (size_t) T*nsc*32) + (size_t) NW*64*16*(dual ? 2 : 1);      // the reduction tiles are re-used per token group
@@ -270,7 +315,7 @@ static inline size_t mmq_lds_bytes(int T, int k, int NW, bool dual, bool q80 = f
 template <int TYPE, bool DUAL, int NW, bool PF, int TG>
 __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int T) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0;
+    constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;     // 32-element blocks, Q8_0 activation image
     const int k = L.k, nsb = Q80 ? k/32 : k/256, nun = Q80 ? (k/32 + 7)/8 : k/256, ldq = k + 16;      // nsb: scales per token, nun: units per row
     int8_t * lq  = (int8_t *) smem;
     float  * ldy = (float *)(smem + (size_t) T*ldq);
@@ -413,7 +458,7 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
 static int mmq_cfg() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMQ_CFG"); return e ? atoi(e) : 0; }(); return v; }
 
 template <int TYPE, bool DUAL, int NW, bool PF, int TG> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
-    const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL, TYPE == GGML_TYPE_Q8_0);
+    const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL, TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0);
     MI_ASSERT(lds <= 160*1024 && L.act.pre);
     int total = 0;
     if (DUAL) total = (L.m[0].rows + 15) / 16;
@@ -432,7 +477,7 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
     const int cfg = mmq_cfg();
     int total = 0;
     for (int i = 0; i < (L.swiglu ? 1 : L.n_mat); ++i) total += (L.m[i].rows + 15) / 16;
-    constexpr bool PF = TYPE != GGML_TYPE_Q6_K && TYPE != GGML_TYPE_Q8_0;      // wide fragments: single-buffered to stay at 4 waves/SIMD
+    constexpr bool PF = TYPE != GGML_TYPE_Q6_K && TYPE != GGML_TYPE_Q8_0 && TYPE != GGML_TYPE_Q4_0;      // wide fragments: single-buffered to stay at 4 waves/SIMD
     if (T > 8) {      // several groups of 8 tokens per pass (prompt / large verification batches): weights and their unpacking are shared
         const int tg = (T + 7) / 8;
         // register budget: 3 groups (24 tokens) per pass, 2 for the dual gate|up kernel
@@ -442,15 +487,18 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
         return;
     }
     // few row groups and a long k: 16 waves per group so that every wave still has <= ~3 super-blocks in sequence
-    const bool wide = !(cfg & 2) && TYPE != GGML_TYPE_Q8_0 && total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu, TYPE == GGML_TYPE_Q8_0) <= 160*1024;
+    const bool wide = !(cfg & 2) && TYPE != GGML_TYPE_Q8_0 && TYPE != GGML_TYPE_Q4_0 && total <= 256 && L.k/256 >= 24 && mmq_lds_bytes(T, L.k, 16, L.swiglu, false) <= 160*1024;
     if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false, 1>(st, T, L); else mmq_launch_one<TYPE, true, 8, false, 1>(st, T, L); }      // gate|up: single-buffered fragments fit two blocks per CU (21.0 -> 18.8 us)
     else          { if (wide) mmq_launch_one<TYPE, false, 16, PF, 1>(st, T, L); else if (cfg & 1) mmq_launch_one<TYPE, false, 8, false, 1>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF, 1>(st, T, L); }
 }
 
 bool mi_mmq_supported(int type, int T, int k, bool swiglu) {
-    if (!(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K || type == GGML_TYPE_Q8_0)) return false;
-    if (T < 1 || T > (swiglu ? 16 : 24) || k % (type == GGML_TYPE_Q8_0 ? 32 : 256)) return false;
-    return mmq_lds_bytes(T, k, 8, true, type == GGML_TYPE_Q8_0) <= 158*1024;
+    const bool b32 = type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q4_0;
+    if (!(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K || b32)) return false;
+    const int tcap = type == GGML_TYPE_Q4_0 ? (swiglu ? 8 : 16) : (swiglu ? 16 : 24);      // register budget of the token-group variants
+    if (T < 1 || T > tcap || k % (b32 ? 32 : 256)) return false;
+    if (type == GGML_TYPE_Q4_0 && T <= 8) return false;        // measured: the dp4a kernel is faster there (21.4 vs 25.0 us at T = 6); the MFMA form pays off by halving the passes at T > 8
+    return mmq_lds_bytes(T, k, 8, true, b32) <= 158*1024;
 }
 // most tokens one pass can take: a multiple of 8 (whole token groups) once above 8
 int mi_mmq_max_tokens(int type, int k, bool swiglu) {
@@ -465,6 +513,7 @@ void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L) {
         case GGML_TYPE_Q5_K: mmq_launch_type<GGML_TYPE_Q5_K>(st, T, L); break;
         case GGML_TYPE_Q6_K: mmq_launch_type<GGML_TYPE_Q6_K>(st, T, L); break;
         case GGML_TYPE_Q8_0: mmq_launch_type<GGML_TYPE_Q8_0>(st, T, L); break;
+        case GGML_TYPE_Q4_0: mmq_launch_type<GGML_TYPE_Q4_0>(st, T, L); break;
         default: MI_ABORT("mmq: unsupported weight type %d", type);
     }
 }

@@ -70,7 +70,7 @@ def test_mul_mat_model_shapes_vs_oracle(ea, gpu, tname, shape, T):
     assert rel(got[:, sel], want) < 2e-5
 
 
-@pytest.mark.parametrize("tname", ["q4_K", "q6_K", "q8_0"])
+@pytest.mark.parametrize("tname", ["q4_K", "q6_K", "q8_0", "q4_0", "q5_K"])
 def test_mul_mat_ragged_and_fused_residual(ea, gpu, tname):
     """rows not a multiple of the rows-per-block, k with a ragged last k-step, fused ADD epilogue, > 8 tokens"""
     t = QTYPES[tname]
