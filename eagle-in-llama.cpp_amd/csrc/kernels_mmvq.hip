@@ -563,6 +563,43 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
         while (tm > 8 && mi_act_image_bytes(type, tm, L0.k) > cache->slot_bytes) tm -= 8;
         if (tm > tmax && mi_mmq_supported(type, tm, L0.k, L0.swiglu != 0)) tmax = tm;
     }
+    // k too long for the LDS image of the matrix-core kernel at the wanted tokens per pass (ffn_down at > 8 tokens, k = 28672 at any T >= 5):
+    // split k into chunks of whole super-blocks, one launch per chunk, every later chunk adding to the output through the residual input.
+    // Plain outputs only (no RoPE / f16 stores / SwiGLU, no folded norm: the row norm needs the whole row).
+    if (kq && cache && cache->pool && L0.n_mat == 1 && !L0.swiglu && L0.m[0].epi == EPI_F32 && !L0.m[0].relu && !L0.act.norm && !L0.act.X2 && Ttot >= mmq_min_tokens()) {
+        const int Tw = Ttot >= 24 ? 24 : (Ttot >= 16 ? 16 : (Ttot > 8 ? 8 : Ttot));
+        if (!mi_mmq_supported(type, Tw, L0.k, false)) {
+            const int nsb = L0.k / 256;
+            int nch = 2, kc = 0;
+            for (; nch <= 8; ++nch) { kc = (nsb + nch - 1) / nch * 256; if (mi_mmq_supported(type, Tw, kc, false) && mi_act_image_bytes(type, Tw, kc) <= cache->slot_bytes) break; }
+            if (nch <= 8) {
+                const size_t blk = mi_traits(type).size;
+                for (int t0 = 0; t0 < Ttot; t0 += Tw) {
+                    const int T = (Ttot - t0) < Tw ? (Ttot - t0) : Tw;
+                    for (int k0 = 0, c = 0; k0 < L0.k; k0 += kc, ++c) {
+                        mmvq_launch L = L0;
+                        L.k = (L0.k - k0) < kc ? (L0.k - k0) : kc;
+                        L.act.X += (size_t) t0 * L.act.xs + k0; L.act.pre = nullptr;
+                        L.m[0].W += (size_t)(k0 / 256) * blk;
+                        L.m[0].out += (size_t) t0 * L.m[0].o_tok;
+                        if (c == 0) { if (L.m[0].res) L.m[0].res += (size_t) t0 * L.m[0].r_tok; }
+                        else { L.m[0].res = (const float *) L.m[0].out; L.m[0].r_tok = L.m[0].o_tok / 4; }
+                        const void * ckey = key ? (const void *)((const char *) key + k0 + 1) : nullptr;       // one image per (tensor, k-chunk)
+                        int hit = -1;
+                        if (ckey) for (int i = 0; i < MI_ACT_SLOTS; ++i) { const auto & e = cache->e[i]; if (e.key == ckey && e.epoch == cache->epoch && e.t0 == t0 && e.T == T && e.kq == kq && e.k == L.k) { hit = i; break; } }
+                        if (hit < 0) {
+                            hit = cache->next; cache->next = (cache->next + 1) % MI_ACT_SLOTS;
+                            mi_quant_act(st, type, T, L.act, L.k, cache->pool + (size_t) hit * cache->slot_bytes);
+                            cache->e[hit] = { ckey, cache->epoch, t0, T, kq, L.k };
+                        }
+                        L.act.pre = cache->pool + (size_t) hit * cache->slot_bytes;
+                        mi_mmq_launch(st, type, T, L);
+                    }
+                }
+                return;
+            }
+        }
+    }
     for (int t0 = 0; t0 < Ttot; t0 += tmax) {
         const int T = (Ttot - t0) < tmax ? (Ttot - t0) : tmax;
         mmvq_launch L = L0;

@@ -76,7 +76,8 @@ def test_mul_mat_ragged_and_fused_residual(ea, gpu, tname):
     t = QTYPES[tname]
     rng = np.random.default_rng(7)
     # T > 8: K-quants take up to 24 tokens per pass (3 groups of 8 on the matrix cores): whole groups, ragged groups, several passes
-    for rows, k, T in [(1, 256, 1), (7, 768, 2), (33, 2816, 3), (130, 5120, 8), (50, 1024, 19), (40, 1024, 9), (48, 2048, 24), (21, 512, 61), (64, 4096, 128)]:
+    for rows, k, T in [(1, 256, 1), (7, 768, 2), (33, 2816, 3), (130, 5120, 8), (50, 1024, 19), (40, 1024, 9), (48, 2048, 24), (21, 512, 61), (64, 4096, 128),
+                       (16, 11008, 24), (16, 11008, 61), (8, 28672, 6)]:      # k too long for one LDS image: k-chunked passes chained through the residual
         w = qdata.random_blocks(t, rows, k, rng)
         x = rng.standard_normal((T, k)).astype(np.float32)
         res = rng.standard_normal((T, rows)).astype(np.float32)
