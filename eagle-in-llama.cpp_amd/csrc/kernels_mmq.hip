@@ -489,7 +489,12 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
     // few row groups (one block each): 16 waves per group, i.e. one super-block per wave at k = 4096 and <= 3 in sequence at k = 11008
     const bool wide = !(cfg & 2) && TYPE != GGML_TYPE_Q8_0 && TYPE != GGML_TYPE_Q4_0 && total <= 256 && L.k/256 >= ((cfg & 8) ? 24 : 16) && mmq_lds_bytes(T, L.k, 16, L.swiglu, false) <= 160*1024;
     if (L.swiglu) { if (wide) mmq_launch_one<TYPE, true, 16, false, 1>(st, T, L); else mmq_launch_one<TYPE, true, 8, false, 1>(st, T, L); }      // gate|up: single-buffered fragments fit two blocks per CU (21.0 -> 18.8 us)
-    else          { if (wide) mmq_launch_one<TYPE, false, 16, PF, 1>(st, T, L); else if (cfg & 1) mmq_launch_one<TYPE, false, 8, false, 1>(st, T, L); else mmq_launch_one<TYPE, false, 8, PF, 1>(st, T, L); }
+    else          {
+        if (wide) mmq_launch_one<TYPE, false, 16, PF, 1>(st, T, L);
+        else if ((cfg & 16) && total > 512 && total <= 1024) mmq_launch_one<TYPE, false, 4, PF, 1>(st, T, L);       // experiment: 4-wave blocks, one round
+        else if (cfg & 1) mmq_launch_one<TYPE, false, 8, false, 1>(st, T, L);
+        else mmq_launch_one<TYPE, false, 8, PF, 1>(st, T, L);
+    }
 }
 
 bool mi_mmq_supported(int type, int T, int k, bool swiglu) {
