@@ -11,15 +11,20 @@
 // (R/ggml/src/ggml-cpu/ggml-cpu-quants.c scalar branches :7020-7078, q5_K/q6_K `#else` tails, :2592-2607),
 // so every int32 partial sum is identical to the CPU's; only the order of the final fp32 adds differs.
 //
-// gfx950 structure (one launch, no scratch):
-//   * prologue: the block quantises the T activation columns straight into LDS (int8 + scales + bsums);
-//     nothing is written to HBM, the separate quantize launch of the reference disappears;
+// This file holds (1) k_mmvq, the dp4a kernel that serves single-token products (and Q4_0 up to 8 tokens), (2) the activation
+// quantisers (k_quant_q8K / k_quant_act) that write the int8 image for the matrix-core kernel (kernels_mmq.hip) and for big
+// T*k, and (3) mi_mmvq_run, the dispatcher between the two kernels (token passes, k-chunks, the scratch-slot cache).
+//
+// k_mmvq on gfx950:
+//   * prologue: with T*k <= 8192 the block quantises the activation columns straight into LDS (int8 + scales + bsums, RMS norm
+//     folded in): nothing goes to HBM and the separate quantize launch of the reference disappears; above that it copies the
+//     image a quantiser launch left in an HBM scratch slot;
 //   * main loop: a wave owns R=2 weight rows at a time; 8 lanes cover one 256-element super-block with
 //     one 16-byte load each (plus the shared 16-byte header), i.e. a wave instruction streams 8
 //     super-blocks = 1152 B of Q4_K contiguous per row; loads are issued for both rows and two
 //     k-steps before the first use so >=8 x 16 B per lane are in flight;
-//   * v_dot4_i32_i8 on packed nibbles, per-lane fp32 partials, one wave64 butterfly per output;
-//   * epilogue optionally adds a residual row (fused GGML_OP_ADD).
+//   * v_dot4_i32_i8 on packed nibbles, per-lane fp32 partials, DPP reductions (no ds_bpermute);
+//   * epilogues: residual / bias (+RELU), RoPE, fp16 cache stores, SwiGLU.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "kernels.h"
