@@ -45,6 +45,7 @@ void mi_mmvq_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L, 
 // matrix-core variant for K-quants (kernels_mmq.hip); needs L.act.pre (image written by mi_quant_act)
 bool mi_mmq_supported(int type, int T, int k, bool swiglu);
 int  mi_mmq_max_tokens(int type, int k, bool swiglu);
+bool mi_mmq_inline_quant(int type, int T, const mmvq_launch & L);      // the kernel quantises in-block: no image needed
 void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L);
 // HIP-event profile hooks around a mat-vec launch (bench.py roofline): begin returns a record index or -1 when off
 int  mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual);

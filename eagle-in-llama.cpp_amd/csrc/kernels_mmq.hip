@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
     mq_frag<TYPE> fa, fb;          // fb unused without PF
     int grp = blockIdx.x, mi = 0, row0 = 0;
     if (grp < total) { set_rows(grp, mi, row0); if (nu > 0) fa.load(unit_ptr(0), kq, nb_left(0)); }      // in flight across the prologue
-    {   // activation image (HBM scratch, written by k_quant_act) -> LDS; token rows padded by 16 bytes against bank conflicts
+    if (L.act.pre) {   // activation image (HBM scratch, written by the quantiser launch) -> LDS; token rows padded by 16 bytes against bank conflicts
         const int nthr = NW*WAVE, n16row = k/16;
         const i32x4 * src = (const i32x4 *) L.act.pre;
         for (int c = threadIdx.x; c < T*n16row; c += nthr) { const int t = c / n16row, o = c - t*n16row; *(i32x4 *)(lq + (size_t) t*ldq + o*16) = src[c]; }
@@ -353,6 +353,30 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmq(const mmvq_launch L, const int 
         if (!Q80) {
             const char * sr = L.act.pre + act_img_bytes(true, T, k) + (TYPE == GGML_TYPE_Q6_K ? (size_t) T*nsb*32 : 0);     // 4-byte aligned only
             for (int c = threadIdx.x; c < T*nsb*2; c += nthr) ((i32x4 *) lrec)[c] = ld16(sr + (size_t) c*16);
+        }
+    } else if constexpr (!Q80) {
+        // in-block quantiser (K-quants, few units per wave -- mi_mmq_inline_quant): a wave per (token, super-block), straight into the LDS
+        // image; saves the quantiser launch in front of this kernel while the first weight loads are already in flight
+        float * sc = (float *) red;                                        // [T] RMS scales (the reduction tiles are free until the first group ends)
+        if (L.act.norm) {
+            for (int t = wave; t < T; t += NW) {
+                const float * row = L.act.X + (size_t) t*L.act.xs;
+                double s2 = 0.0;
+                for (int i = lane*4; i < k; i += 256) { const float4 x = *(const float4 *)(row + i); s2 += (double)(x.x*x.x); s2 += (double)(x.y*x.y); s2 += (double)(x.z*x.z); s2 += (double)(x.w*x.w); }
+                const double tot = wave_sum_d(s2);
+                if (lane == 0) sc[t] = 1.0f / sqrtf((float)(tot / (double) k) + L.act.eps);
+            }
+            __syncthreads();
+        }
+        for (int u = wave; u < T*nsb; u += NW) {
+            const int t = u / nsb, sb = u - t*nsb, e = sb*256 + lane*4;
+            float4 v = *(const float4 *)(L.act.X + (size_t) t*L.act.xs + e);
+            if (L.act.norm) {
+                const float s1 = sc[t];
+                v.x *= s1; v.y *= s1; v.z *= s1; v.w *= s1;
+                if (L.act.norm_w) { const float4 w = *(const float4 *)(L.act.norm_w + e); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+            }
+            quant_q8K_unit(v, lane, t, sb, ldq, nsb, lq, ldy, nullptr, TYPE == GGML_TYPE_Q6_K ? nullptr : lrec, TYPE == GGML_TYPE_Q6_K ? lrec : nullptr);
         }
     }
     __syncthreads();
@@ -459,7 +483,7 @@ static int mmq_cfg() { static const int v = [] { const char * e = getenv("GGML_M
 
 template <int TYPE, bool DUAL, int NW, bool PF, int TG> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
     const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL, TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0);
-    MI_ASSERT(lds <= 160*1024 && L.act.pre);
+    MI_ASSERT(lds <= 160*1024 && (L.act.pre || mi_mmq_inline_quant(TYPE, T, L)));
     int total = 0;
     if (DUAL) total = (L.m[0].rows + 15) / 16;
     else for (int i = 0; i < L.n_mat; ++i) total += (L.m[i].rows + 15) / 16;
@@ -497,6 +521,19 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
     }
 }
 
+// Optional: the kernel quantises the activations itself (a wave per (token, super-block)) instead of reading an image a quantiser
+// launch prepared, when there are at most GGML_MI355X_MMQ_INLINE_UPW units per wave.  OFF by default (0): measured on the 7B
+// verification it costs more than the launch it saves (951 vs 1015 tokens/s at 8 units per wave: every block of wo / qkv repeats
+// the quantisation).  Mirrors the block shape mmq_launch_type picks (16 waves for single-matrix launches with <= 256 row groups).
+bool mi_mmq_inline_quant(int type, int T, const mmvq_launch & L) {
+    static const int upw = [] { const char * e = getenv("GGML_MI355X_MMQ_INLINE_UPW"); return e ? atoi(e) : 0; }();
+    if (upw <= 0 || !(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K)) return false;
+    if (T > 8 || L.act.X2 || L.k > 8192) return false;
+    int total = 0;
+    for (int i = 0; i < (L.swiglu ? 1 : L.n_mat); ++i) total += (L.m[i].rows + 15) / 16;
+    const int nw = (!L.swiglu && total <= 256 && L.k/256 >= 16) ? 16 : 8;
+    return T * (L.k/256) <= upw * nw;
+}
 bool mi_mmq_supported(int type, int T, int k, bool swiglu) {
     const bool b32 = type == GGML_TYPE_Q8_0 || type == GGML_TYPE_Q4_0;
     if (!(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K || b32)) return false;

@@ -613,7 +613,8 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
         for (int i = 0; i < L.n_mat; ++i) { L.m[i].out += (size_t) t0 * L.m[i].o_tok; if (L.m[i].res) L.m[i].res += (size_t) t0 * L.m[i].r_tok; }
         if (L.rope.pos) L.rope.pos += t0;
         const bool mmq = cache && cache->pool && T >= mmq_min_tokens() && mi_mmq_supported(type, T, L.k, L.swiglu != 0) && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes;
-        if (cache && cache->pool && (mmq || (int64_t) T * L.k > PRE_MIN_ELEMS) && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes) {
+        const bool inl = mmq && mi_mmq_inline_quant(type, T, L);
+        if (!inl && cache && cache->pool && (mmq || (int64_t) T * L.k > PRE_MIN_ELEMS) && mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes) {
             int hit = -1;
             if (key) for (int i = 0; i < MI_ACT_SLOTS; ++i) { const auto & e = cache->e[i]; if (e.key == key && e.epoch == cache->epoch && e.t0 == t0 && e.T == T && e.kq == kq && e.k == L.k) { hit = i; break; } }
             if (hit < 0) {

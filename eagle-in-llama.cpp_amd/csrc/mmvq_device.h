@@ -118,11 +118,12 @@ __device__ __forceinline__ void quant_q8K_unit(const float4 v4, int lane, int t,
     }
     *(int *)(q + (size_t) t*k + sb*256 + lane*4) = packed;
     s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s);
-    if ((lane & 3) == 0) bs[t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
+    if (bs && (lane & 3) == 0) bs[t*(k/16) + sb*16 + (lane >> 2)] = (short) s;
     if (lane == 0) d[t*nsb + sb] = dd;
-    if (rec32) {                                                       // split sums for the matrix-core kernel
-        int8_t * r32 = (int8_t *) rec32 + (size_t)(t*nsb + sb)*32, * r16 = (int8_t *) rec16 + (size_t)(t*nsb + sb)*32;
-        if ((lane & 3) == 0) { r16[lane >> 2] = (int8_t)(s & 127); r16[16 + (lane >> 2)] = (int8_t)(s >> 7); }
+    // split sums for the matrix-core kernel (either record may be absent)
+    if (rec16) { int8_t * r16 = (int8_t *) rec16 + (size_t)(t*nsb + sb)*32; if ((lane & 3) == 0) { r16[lane >> 2] = (int8_t)(s & 127); r16[16 + (lane >> 2)] = (int8_t)(s >> 7); } }
+    if (rec32) {
+        int8_t * r32 = (int8_t *) rec32 + (size_t)(t*nsb + sb)*32;
         const int s2 = s + dpp_i<DPP_HMIR>(s);                          // quads are uniform: the other quad of the 8 lanes
         if ((lane & 7) == 0) { r32[lane >> 3] = (int8_t)(s2 & 127); r32[16 + (lane >> 3)] = (int8_t)(s2 >> 7); }
         if ((lane & 7) == 4) { r32[8 + (lane >> 3)] = 0; r32[24 + (lane >> 3)] = 0; }
