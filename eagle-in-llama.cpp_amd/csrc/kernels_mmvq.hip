@@ -416,6 +416,7 @@ void mi_quant_act(hipStream_t st, int type, int T, const act_src & a0, int k, ch
     }
     for (int t0 = 0; t0 < T; t0 += 8) {                       // images of more than 8 tokens (matrix-core kernel) are filled 8 tokens per launch
         act_src a = a0; a.X += (size_t) t0 * a.xs;
+        if (a.X2) a.X2 += (size_t) t0 * a.xs2;                 // the second CONCAT source advances with the tokens too
         const int n = T - t0 < 8 ? T - t0 : 8;
         if (mi_traits(type).blck == 256) quant_act_T<true>(st, n, a, k, out, T, t0); else quant_act_T<false>(st, n, a, k, out, T, t0);
     }
@@ -609,6 +610,7 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
         const int T = (Ttot - t0) < tmax ? (Ttot - t0) : tmax;
         mmvq_launch L = L0;
         L.act.X += (size_t) t0 * L.act.xs;
+        if (L.act.X2) L.act.X2 += (size_t) t0 * L.act.xs2;    // CONCAT(X, X2): both halves are token-major
         L.act.pre = nullptr;
         for (int i = 0; i < L.n_mat; ++i) { L.m[i].out += (size_t) t0 * L.m[i].o_tok; if (L.m[i].res) L.m[i].res += (size_t) t0 * L.m[i].r_tok; }
         if (L.rope.pos) L.rope.pos += t0;

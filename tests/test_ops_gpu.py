@@ -200,7 +200,7 @@ def test_eagle_fc_front_fused_vs_reference_backend(ea, gpu, ref_cpu):
     (two-source quantiser, broadcast bias, relu epilogue); same graph on the reference CPU backend.  T = 1 takes the dp4a kernel
     with its in-block quantiser, T = 6 the quantise-once image + matrix-core kernel."""
     rng = np.random.default_rng(21)
-    for t, T in [(12, 1), (12, 6), (14, 3), (8, 2)]:
+    for t, T in [(12, 1), (12, 6), (14, 3), (8, 2), (12, 9), (12, 25), (14, 61), (8, 25), (2, 9), (2, 61)]:   # T > 8 / > 24: several token passes -- both CONCAT sources must advance
         E = 1024
         w = qdata.random_blocks(t, E, 2 * E, rng)
         e = rng.standard_normal((T, E)).astype(np.float32); hdn = rng.standard_normal((T, E)).astype(np.float32)
