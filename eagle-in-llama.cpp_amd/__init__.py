@@ -233,6 +233,17 @@ class Graph:
         assert arr.nbytes == n, f"set: {arr.nbytes} bytes given, tensor spans {n}"
         host().eh_set(self.h, t, arr.ctypes.data_as(C.c_void_p), 0, n)
 
+    def set_at(self, t, arr, offset):
+        """partial write: raw bytes of `arr` at byte `offset` of the tensor (ggml_backend_tensor_set with an offset)"""
+        arr = np.ascontiguousarray(arr)
+        assert offset + arr.nbytes <= self.nbytes(t)
+        host().eh_set(self.h, t, arr.ctypes.data_as(C.c_void_p), offset, arr.nbytes)
+
+    def get_at(self, t, offset, nbytes):
+        out = np.empty(nbytes, dtype=np.uint8)
+        host().eh_get(self.h, t, out.ctypes.data_as(C.c_void_p), offset, nbytes)
+        return out
+
     def get(self, t, dtype=np.float32):
         n = self.nbytes(t)
         out = np.empty(n // np.dtype(dtype).itemsize, dtype=dtype)

@@ -15,6 +15,9 @@
 #include <vector>
 #include <string>
 #include <dlfcn.h>
+#include "tile_layout.h"
+
+#define MI_MAX_DEVICES 16
 
 // The host's own constructor for buffer objects (R/ggml/src/ggml-backend.cpp "ggml_backend_buffer_init").
 // Resolved from the process that loaded us when it is a ggml host, so that the object is created and
@@ -28,7 +31,6 @@ static ggml_backend_buffer_t make_buffer(ggml_backend_buffer_type_t buft, const 
     return b;
 }
 
-#define MI_MAX_DEVICES 16
 static int g_ndev = -1;
 static ggml_backend_device       g_devs[MI_MAX_DEVICES];
 static mi_device_ctx             g_devctx[MI_MAX_DEVICES];
@@ -39,6 +41,78 @@ static ggml_guid                 g_guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 
 
 static void set_device(int dev) { HIP_CHECK(hipSetDevice(dev)); }
 
+// ============================================================ weight re-layout state (tile_layout.h, kernels_tile.hip)
+// A quantised weight matrix keeps ggml's row-major blocks until the first MUL_MAT that reads it; mi_ensure_tiled() then permutes
+// it once, in place, into 16-row x 1-unit tiles and tags the tensor through ggml_tensor::extra (which belongs to the backend
+// that owns the buffer, as in the reference: ggml-cuda.cu:840).  Every other way to see the bytes goes through mi_untile() or
+// an on-the-fly inverse, so hosts keep observing ggml's layout: get_tensor, cpy_tensor, partial set_tensor / memset.
+static char g_tag_tiled, g_tag_notile;
+static std::mutex g_tile_mu;
+static void * g_tile_scratch[MI_MAX_DEVICES] = {};
+static size_t g_tile_scratch_size[MI_MAX_DEVICES] = {};
+static bool tile_disabled() { static const bool v = getenv("GGML_MI355X_NO_TILE") != nullptr; return v; }
+static void * tile_scratch(int dev, size_t n) {
+    if (n > g_tile_scratch_size[dev]) {
+        if (g_tile_scratch[dev]) HIP_CHECK(hipFree(g_tile_scratch[dev]));
+        HIP_CHECK(hipMalloc(&g_tile_scratch[dev], n)); g_tile_scratch_size[dev] = n;
+    }
+    return g_tile_scratch[dev];
+}
+static inline ggml_tensor * tile_root(const ggml_tensor * t) { return (ggml_tensor *)(t->view_src ? t->view_src : t); }
+bool mi_is_tiled(const ggml_tensor * t) { return t->extra == (void *) &g_tag_tiled; }
+bool mi_tile_eligible(const ggml_tensor * w) {
+    if (tile_disabled() || !w || w->view_src || w->op != GGML_OP_NONE || !w->data || !mi_buffer_is_ours(w->buffer)) return false;
+    if (w->extra == (void *) &g_tag_notile) return false;
+    if (w->buffer->usage == GGML_BACKEND_BUFFER_USAGE_COMPUTE) return false;        // scheduler copies of host-resident weights are rewritten every graph
+    const int ub = mi_unit_bytes(w->type);
+    if (!ub || w->ne[2] != 1 || w->ne[3] != 1 || (w->ne[1] % 16) || (w->ne[0] % 256) || w->ne[1] < 16) return false;
+    return w->nb[0] == (size_t) mi_traits(w->type).size && w->nb[1] == mi_row_size(w->type, w->ne[0]);
+}
+// in place: raw -> tiled (fwd) or tiled -> raw; everything on the device is drained first (first use / rare paths only)
+static void tile_convert(ggml_tensor * w, bool fwd) {
+    mi_buffer_ctx * c = (mi_buffer_ctx *) w->buffer->context; set_device(c->device);
+    const size_t n = mi_nbytes(w);
+    HIP_CHECK(hipDeviceSynchronize());
+    void * tmp = tile_scratch(c->device, n);
+    HIP_CHECK(hipMemcpyAsync(tmp, w->data, n, hipMemcpyDeviceToDevice, hipStreamPerThread));
+    mi_tile_permute(hipStreamPerThread, tmp, w->data, w->type, w->ne[1], w->ne[0], fwd);
+    HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+bool mi_ensure_tiled(ggml_tensor * w) {
+    if (mi_is_tiled(w)) return true;
+    std::lock_guard<std::mutex> lk(g_tile_mu);
+    if (mi_is_tiled(w)) return true;
+    if (!mi_tile_eligible(w)) return false;
+    tile_convert(w, true);
+    w->extra = (void *) &g_tag_tiled;
+    return true;
+}
+// back to ggml's layout; `never_again` pins the tensor there (a view of it is used as a mat-mul operand)
+void mi_untile(ggml_tensor * t, bool never_again) {
+    ggml_tensor * w = tile_root(t);
+    std::lock_guard<std::mutex> lk(g_tile_mu);
+    if (mi_is_tiled(w)) { tile_convert(w, false); w->extra = nullptr; }
+    if (never_again) w->extra = (void *) &g_tag_notile;
+}
+// the whole tensor is about to be overwritten: no need to convert what is there
+static void tile_forget(ggml_tensor * w) { std::lock_guard<std::mutex> lk(g_tile_mu); if (mi_is_tiled(w)) w->extra = nullptr; }
+static void before_write(ggml_tensor * t, size_t off, size_t size) {
+    ggml_tensor * w = tile_root(t);
+    if (!mi_is_tiled(w)) return;
+    if (t == w && off == 0 && size == mi_nbytes(w)) tile_forget(w); else mi_untile(w, false);
+}
+// ggml-layout bytes [off, off+size) of a tiled tensor (or of a view into one) -> host
+static void tiled_read(const ggml_tensor * t, void * data, size_t off, size_t size) {
+    ggml_tensor * w = tile_root(t);
+    std::lock_guard<std::mutex> lk(g_tile_mu);
+    mi_buffer_ctx * c = (mi_buffer_ctx *) w->buffer->context; set_device(c->device);
+    HIP_CHECK(hipDeviceSynchronize());
+    char * tmp = (char *) tile_scratch(c->device, mi_nbytes(w));
+    mi_tile_permute(hipStreamPerThread, w->data, tmp, w->type, w->ne[1], w->ne[0], false);
+    HIP_CHECK(hipMemcpyAsync(data, tmp + ((const char *) t->data - (const char *) w->data) + off, size, hipMemcpyDeviceToHost, hipStreamPerThread));
+    HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+
 // ============================================================ device buffer
 static void buf_free(ggml_backend_buffer_t b) {
     mi_buffer_ctx * c = (mi_buffer_ctx *) b->context;
@@ -47,24 +121,32 @@ static void buf_free(ggml_backend_buffer_t b) {
     delete c;
 }
 static void * buf_get_base(ggml_backend_buffer_t b) { return ((mi_buffer_ctx *) b->context)->base; }
-static void buf_init_tensor(ggml_backend_buffer_t, ggml_tensor *) { /* native ggml layout in HBM: nothing to attach */ }
+static void buf_init_tensor(ggml_backend_buffer_t, ggml_tensor * t) {
+    // (re)allocation: whatever lived at this address before is gone, and with it any layout tag of ours
+    if (!t->view_src) t->extra = nullptr;
+}
 static void buf_memset_tensor(ggml_backend_buffer_t b, ggml_tensor * t, uint8_t v, size_t off, size_t size) {
     mi_buffer_ctx * c = (mi_buffer_ctx *) b->context; set_device(c->device);
+    if (!(off == 0 && size == mi_nbytes(t))) before_write(t, off, size);           // a constant fill of the whole tensor is layout-invariant
     HIP_CHECK(hipMemsetAsync((char *) t->data + off, v, size, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
 static void buf_set_tensor(ggml_backend_buffer_t b, ggml_tensor * t, const void * data, size_t off, size_t size) {
     mi_buffer_ctx * c = (mi_buffer_ctx *) b->context; set_device(c->device);
+    before_write(t, off, size);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, size, hipMemcpyHostToDevice, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
 static void buf_get_tensor(ggml_backend_buffer_t b, const ggml_tensor * t, void * data, size_t off, size_t size) {
     mi_buffer_ctx * c = (mi_buffer_ctx *) b->context; set_device(c->device);
+    if (mi_is_tiled(tile_root(t))) { tiled_read(t, data, off, size); return; }
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + off, size, hipMemcpyDeviceToHost, hipStreamPerThread));
     HIP_CHECK(hipStreamSynchronize(hipStreamPerThread));
 }
 static bool buf_cpy_tensor(ggml_backend_buffer_t b, const ggml_tensor * src, ggml_tensor * dst) {
     if (!mi_buffer_is_ours(src->buffer)) return false;                 // caller falls back to get+set
+    if (mi_is_tiled(tile_root(src))) return false;                     // get_tensor hands out ggml's layout
+    before_write(dst, 0, mi_nbytes(dst));
     mi_buffer_ctx * sc = (mi_buffer_ctx *) src->buffer->context, * dc = (mi_buffer_ctx *) b->context;
     const size_t n = mi_nbytes(src);
     set_device(dc->device);
@@ -155,16 +237,20 @@ static void be_free(ggml_backend_t b) {
 }
 static void be_set_async(ggml_backend_t b, ggml_tensor * t, const void * data, size_t off, size_t size) {
     mi_backend_ctx * c = (mi_backend_ctx *) b->context; set_device(c->device);
+    before_write(t, off, size);
     HIP_CHECK(hipMemcpyAsync((char *) t->data + off, data, size, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_async(ggml_backend_t b, const ggml_tensor * t, void * data, size_t off, size_t size) {
     mi_backend_ctx * c = (mi_backend_ctx *) b->context; set_device(c->device);
+    if (mi_is_tiled(tile_root(t))) { tiled_read(t, data, off, size); return; }
     HIP_CHECK(hipMemcpyAsync(data, (const char *) t->data + off, size, hipMemcpyDeviceToHost, c->stream));
 }
 static bool be_is_ours(ggml_backend_t b);
 static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const ggml_tensor * src, ggml_tensor * dst) {
     if (!be_is_ours(bs) || !be_is_ours(bd)) return false;
     if (!mi_buffer_is_ours(src->buffer) || !mi_buffer_is_ours(dst->buffer)) return false;
+    if (mi_is_tiled(tile_root(src))) return false;
+    before_write(dst, 0, mi_nbytes(dst));
     mi_backend_ctx * cs = (mi_backend_ctx *) bs->context, * cd = (mi_backend_ctx *) bd->context;
     const size_t n = mi_nbytes(dst);
     if (bs == bd) {

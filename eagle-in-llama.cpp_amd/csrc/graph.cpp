@@ -334,10 +334,12 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
     // ---- collect siblings: later MUL_MATs with the same src1, same weight type
     member mem[3]; int nm = 0;
     mem[nm].node = i; mem[nm].mm = t; nm++;
+    const bool tiled0 = mi_ensure_tiled(t->src[0]);                       // first use re-lays the weight out (tile_layout.h); a launch is all-tiled or all row-major
     for (int j = i + 1; j < c.n && j < i + 14 && nm < 3; ++j) {
         const ggml_tensor * u = c.g->nodes[j];
         if (c.done[j] || u->op != GGML_OP_MUL_MAT || u->src[1] != x) continue;
         if (u->src[0]->type != w0->type || u->src[0]->ne[0] != k || u->src[0]->ne[2] != 1 || u->src[0]->ne[3] != 1 || !mi_supports_op(0, u)) continue;
+        if (mi_ensure_tiled(u->src[0]) != tiled0) continue;
         mem[nm].node = j; mem[nm].mm = u; nm++;
     }
     // ---- SwiGLU: gate (this node) -> SILU -> MUL(silu, up)
@@ -357,7 +359,8 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
                     // the product is written at `at` instead of `upto`: must not alias anything still needed, nor our own inputs
                     if (write_conflicts(c, mul->data, mi_nbytes(mul), at, upto, skip)) break;
                     if (overlap(mul->data, mi_nbytes(mul), ap.src.X, (size_t) T * ap.src.xs * 4)) break;
-                    mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = 2; L.swiglu = 1;
+                    mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = 2; L.swiglu = 1; L.tiled = tiled0;
+                    if (tiled0 && ap.rms) { L.act.norm_out = (float *) x->data; L.act.norm_os = x->nb[1]/4; }      // the folded norm is materialised as a side effect
                     member g0 = mem[0], g1 = mem[q]; g0.epi = EPI_F32; g0.out = mul; g0.res = nullptr; g1.epi = EPI_F32; g1.out = mul; g1.res = nullptr;
                     fill_mat(L.m[0], g0); fill_mat(L.m[1], g1);
                     L.m[0].o_row = 4; L.m[0].o_tok = mul->nb[1];
@@ -403,7 +406,8 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
         if (clash) { mi_op_concat(st, x); ap.src.X = (const float *) x->data; ap.src.xs = x->nb[1]/4; ap.src.X2 = nullptr; ap.src.xs2 = 0; ap.src.ksplit = 0; }
     }
     { static const bool dbg = getenv("GGML_MI355X_DEBUG_GROUP") != nullptr; if (dbg) MI_LOG("group at %s: %d siblings, %d kept, T=%d", t->name, nm, keep, T); }
-    mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = keep; L.swiglu = 0;
+    mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = keep; L.swiglu = 0; L.tiled = tiled0;
+    if (tiled0 && ap.rms) { L.act.norm_out = (float *) x->data; L.act.norm_os = x->nb[1]/4; }
     for (int q = 0; q < keep; ++q) fill_mat(L.m[q], sel[q]);
     if (rope0) {
         L.rope.pos = (const int32_t *) pos->data; L.rope.head_dim = (int) rope0->ne[0];
@@ -485,6 +489,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
             } break;
             case GGML_OP_MUL_MAT: {
                 if (mi_mul_mat_q_supported_type(t->src[0]->type)) {
+                    if (t->src[0]->view_src && mi_is_tiled(t->src[0]->view_src)) mi_untile(t->src[0], true);      // a view into a re-laid-out weight: back to ggml's layout for good
                     if (!run_mmvq_group(ctx, c, i, fuse)) mi_op_mul_mat_q(st, t, nullptr, t, ctx->act_cache);
                 } else {
                     if (fuse && run_attention(ctx, c, i)) break;

@@ -24,6 +24,7 @@ struct act_src {                        // activations of a mat-vec launch (see 
     const float * X; int64_t xs; const float * norm_w; int norm; float eps;
     const char * pre;                  // non-NULL: activations already quantised by mi_quant_act (image in HBM scratch)
     const float * X2; int64_t xs2; int ksplit;   // X2 non-NULL: the activations are CONCAT(X, X2) along k, X2 starting at element ksplit (EAGLE's [embd; hidd])
+    float * norm_out; int64_t norm_os;  // with `norm`: where the folded RMS_NORM [* w] result is materialised as a side effect (row stride in floats); tiled kernel only
 };
 struct mmvq_mat {
     const char * W; int64_t row_bytes; int rows; int epi;
@@ -32,7 +33,7 @@ struct mmvq_mat {
     int relu;                           // EPI_F32: max(x, 0) after the residual / bias (fused GGML_UNARY_OP_RELU)
 };
 struct mmvq_rope { const int32_t * pos; int head_dim; float theta_scale, freq_scale, attn_factor; };
-struct mmvq_launch { act_src act; int k; int n_mat; int swiglu; mmvq_mat m[3]; mmvq_rope rope; };
+struct mmvq_launch { act_src act; int k; int n_mat; int swiglu; mmvq_mat m[3]; mmvq_rope rope; int tiled; };   // tiled: every W is in the layout of tile_layout.h (kernels_mmt.hip)
 #define MI_ACT_SLOTS 8
 struct mi_act_cache {                  // quantised-activation images in HBM scratch (see mi_mmvq_run)
     char * pool = nullptr; size_t slot_bytes = 0; int next = 0; uint64_t epoch = 0;
@@ -47,6 +48,9 @@ bool mi_mmq_supported(int type, int T, int k, bool swiglu);
 int  mi_mmq_max_tokens(int type, int k, bool swiglu);
 bool mi_mmq_inline_quant(int type, int T, const mmvq_launch & L);      // the kernel quantises in-block: no image needed
 void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L);
+// tiled-layout kernel (kernels_mmt.hip): any token count, in-kernel activation quantiser for small T*k
+void mi_mmt_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L, mi_act_cache * cache, const void * key);
+double mi_launch_bytes(const mmvq_launch & L, int T, bool dual);
 // HIP-event profile hooks around a mat-vec launch (bench.py roofline): begin returns a record index or -1 when off
 int  mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual);
 void mi_prof_end(hipStream_t st, int idx);

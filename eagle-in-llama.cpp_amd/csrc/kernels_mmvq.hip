@@ -474,7 +474,7 @@ extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_profil
     return n;
 }
 // algorithmic bytes of one launch: weights once + fp32 activations once + outputs once
-static double launch_bytes(const mmvq_launch & L, int T, bool dual) {
+double mi_launch_bytes(const mmvq_launch & L, int T, bool dual) {
     double b = (double) T * L.k * 4;
     const int nm = dual ? 2 : L.n_mat;
     for (int i = 0; i < nm; ++i) b += (double) L.m[i].rows * L.m[i].row_bytes;
@@ -492,7 +492,7 @@ int mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         if (g_prof.size() % 64 == 0) { prof_rec c; HIP_CHECK(hipEventCreate(&c.a)); HIP_CHECK(hipEventCreate(&c.b)); c.bytes = 0; HIP_CHECK(hipEventRecord(c.a, st)); HIP_CHECK(hipEventRecord(c.b, st)); g_prof_cal.push_back(c); }
     }
-    prof_rec r; HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b)); r.bytes = launch_bytes(L, T, dual);
+    prof_rec r; HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b)); r.bytes = mi_launch_bytes(L, T, dual);
     HIP_CHECK(hipEventRecord(r.a, st));
     std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(r);
     return (int) g_prof.size() - 1;
@@ -560,6 +560,7 @@ static int mmq_min_tokens() {
     return v;
 }
 void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_act_cache * cache, const void * key) {
+    if (L0.tiled) { mi_mmt_run(st, type, Ttot, L0, cache, key); return; }
     int tmax = mi_mmvq_max_tokens(type, L0.k);
     MI_ASSERT(tmax >= 1);
     const int kq = mi_traits(type).blck == 256;
@@ -654,6 +655,7 @@ void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor 
         L.m[0].W = (const char *) w->data + (i2/r2)*w->nb[2] + (i3/r3)*w->nb[3]; L.m[0].row_bytes = w->nb[1]; L.m[0].rows = rows;
         L.m[0].epi = EPI_F32; L.m[0].out = (char *) out->data + i2*out->nb[2] + i3*out->nb[3]; L.m[0].o_row = 4; L.m[0].o_tok = out->nb[1];
         if (residual) { L.m[0].res = (const float *)((const char *) residual->data + i2*residual->nb[2] + i3*residual->nb[3]); L.m[0].r_tok = residual->nb[1]/4; }
+        L.tiled = mi_ensure_tiled((ggml_tensor *) w) ? 1 : 0;              // eligible weights are re-laid out at their first use (tile_layout.h)
         mi_mmvq_run(st, w->type, (int) Ttot, L, cache, (x->ne[2] == 1 && x->ne[3] == 1) ? (const void *) x : nullptr);
     }
 }

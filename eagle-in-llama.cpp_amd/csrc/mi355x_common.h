@@ -104,6 +104,13 @@ bool mi_buft_is_ours(ggml_backend_buffer_type_t buft);
 bool mi_buft_is_our_host(ggml_backend_buffer_type_t buft);
 void * mi_scratch(mi_backend_ctx * ctx, size_t size);       // grow-only scratch on ctx->device
 
+// weight re-layout (backend.cpp / kernels_tile.hip / tile_layout.h)
+bool mi_is_tiled(const ggml_tensor * t);                    // t itself carries the tiled tag
+bool mi_tile_eligible(const ggml_tensor * w);
+bool mi_ensure_tiled(ggml_tensor * w);                      // first MUL_MAT use: permute in place; returns whether w is tiled now
+void mi_untile(ggml_tensor * t, bool never_again);         // back to ggml's layout (t or the tensor it views)
+void mi_tile_permute(hipStream_t st, const void * src, void * dst, int type, int64_t rows, int64_t k, bool fwd);
+
 // graph.cpp
 enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g);
 bool             mi_supports_op(int device, const ggml_tensor * op);

@@ -1,0 +1,93 @@
+"""Weight re-layout on the GPU: a quantised weight is permuted into 16-row tiles at its first MUL_MAT
+(csrc/tile_layout.h, kernels_tile.hip) and the matrix-core kernel reads the tiles (kernels_mmt.hip) -- but every byte a host
+can observe through the ABI (get_tensor, partial get / set) keeps ggml's row-major block layout."""
+import numpy as np
+import pytest
+
+import oracle as orc
+import qdata
+
+pytestmark = pytest.mark.gpu
+QTYPES = {"q4_0": 2, "q8_0": 8, "q4_K": 12, "q5_K": 13, "q6_K": 14}
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(np.asarray(b, np.float64)).max() + 1e-30))
+
+
+@pytest.mark.parametrize("tname", list(QTYPES))
+def test_tiled_weight_round_trip_and_partial_io(ea, gpu, tname):
+    t = QTYPES[tname]
+    rng = np.random.default_rng(31)
+    rows, k, T = 64, 1024, 3
+    w = qdata.random_blocks(t, rows, k, rng)
+    x = rng.standard_normal((T, k)).astype(np.float32)
+    g = ea.Graph(gpu, ea.USAGE_WEIGHTS)
+    a, b = g.tensor(t, k, rows), g.tensor(ea.F32, k, T)
+    c = g.mul_mat(a, b)
+    g.alloc(); g.set(a, w); g.set(b, x)
+    assert np.array_equal(g.get(a, np.uint8), w)                      # before the first use: plain copy
+    g.compute()                                                       # first use: the weight is re-laid out in place
+    assert rel(g.get(c).reshape(T, rows), orc.mul_mat_q(t, w, x, k, rows)) < 2e-5
+    assert np.array_equal(g.get(a, np.uint8), w)                      # the host still sees ggml's layout
+    rb = orc.row_bytes(t, k)
+    assert np.array_equal(g.get_at(a, 3 * rb + 10, 2 * rb + 7), w[3 * rb + 10: 5 * rb + 17])
+    # partial write into a tiled tensor, then compute again
+    w2 = w.copy()
+    patch = qdata.random_blocks(t, 3, k, rng)
+    w2[5 * rb: 8 * rb] = patch
+    g.set_at(a, patch, 5 * rb)
+    assert np.array_equal(g.get(a, np.uint8), w2)
+    g.compute()
+    assert rel(g.get(c).reshape(T, rows), orc.mul_mat_q(t, w2, x, k, rows)) < 2e-5
+    assert np.array_equal(g.get(a, np.uint8), w2)
+    # whole-tensor overwrite of a tiled tensor
+    g.set(a, w)
+    g.compute()
+    assert rel(g.get(c).reshape(T, rows), orc.mul_mat_q(t, w, x, k, rows)) < 2e-5
+
+
+@pytest.mark.parametrize("tname", ["q4_K", "q6_K", "q8_0"])
+@pytest.mark.parametrize("T", [1, 6, 8])
+def test_folded_norm_is_materialised(ea, gpu, tname, T):
+    """RMS_NORM -> MUL(w) folded into the mat-vec prologue: the normalised tensor is still written (block 0), so a reader outside
+    the graph view finds it (graph.cpp reader counting)."""
+    t = QTYPES[tname]
+    rng = np.random.default_rng(5)
+    rows, k = 256, 4096
+    w = qdata.random_blocks(t, rows, k, rng)
+    x = (rng.standard_normal((T, k)) * 3).astype(np.float32)
+    nw = rng.standard_normal(k).astype(np.float32)
+    g = ea.Graph(gpu, ea.USAGE_WEIGHTS)
+    a, b, nwt = g.tensor(t, k, rows), g.tensor(ea.F32, k, T), g.tensor(ea.F32, k)
+    xn = g.mul(g.rms_norm(b, 1e-6), nwt)
+    c = g.mul_mat(a, xn)
+    g.alloc(); g.set(a, w); g.set(b, x); g.set(nwt, nw); g.compute()
+    want_n = orc.rms_norm(x, 1e-6) * nw
+    assert rel(g.get(xn).reshape(T, k), want_n) < 2e-6
+    assert rel(g.get(c).reshape(T, rows), orc.mul_mat_q(t, w, want_n.astype(np.float32), k, rows)) < 2e-5
+
+
+@pytest.mark.parametrize("tname", list(QTYPES))
+def test_tiled_kernel_token_counts_and_long_k(ea, gpu, tname):
+    """token passes (1..8 in-kernel quantiser, 9..24 token groups through the HBM image, > 24 several passes), k-chunks when one LDS
+    image cannot hold k, fused residual"""
+    t = QTYPES[tname]
+    rng = np.random.default_rng(17)
+    for rows, k, T in [(16, 256, 1), (32, 768, 2), (48, 4096, 7), (64, 8192, 4), (32, 8192, 5), (16, 11008 // 256 * 256, 6), (48, 2048, 9), (32, 1024, 24), (16, 512, 61),
+                       (16, 28672, 6), (16, 11264, 24)]:
+        w = qdata.random_blocks(t, rows, k, rng)
+        x = rng.standard_normal((T, k)).astype(np.float32)
+        res = rng.standard_normal((T, rows)).astype(np.float32)
+        want = orc.mul_mat_q(t, w, x, k, rows)
+        for r in (None, res):
+            g = ea.Graph(gpu, ea.USAGE_WEIGHTS)
+            a, b = g.tensor(t, k, rows), g.tensor(ea.F32, k, T)
+            c = g.mul_mat(a, b); out = c
+            if r is not None:
+                rt = g.tensor(ea.F32, rows, T); out = g.add(c, rt)
+            g.alloc(); g.set(a, w); g.set(b, x)
+            if r is not None:
+                g.set(rt, r)
+            g.compute()
+            assert rel(g.get(out).reshape(T, rows), want + (0 if r is None else r)) < 2e-5, (tname, rows, k, T, r is not None)
