@@ -191,14 +191,17 @@ static bool can_defer_norm(const gctx & c, int i) {
     const ggml_tensor * rms = c.g->nodes[i];
     const ggml_tensor * a = rms->src[0];
     if (!is_f32(a) || a->nb[0] != 4 || a->ne[2] != 1 || a->ne[3] != 1 || (a->nb[1] % 16) || ((uintptr_t) a->data % 16)) return false;
-    if ((rms->flags & GGML_TENSOR_FLAG_OUTPUT) || name_is_result(rms)) return false;
+    // a norm the host will read back (graph output, "result_norm": the hidden-state channel) can still be folded when every reader is a
+    // TILED launch: those write the normalised tensor as a side effect (kernels_mmt.hip, k_quant_q8K)
+    bool wanted = (rms->flags & GGML_TENSOR_FLAG_OUTPUT) || name_is_result(rms);
     const ggml_tensor * x = rms;
     if (c.n_uses(rms) == 1) {
         const ggml_tensor * m = c.g->nodes[c.last_use(rms)];
         if (m->op == GGML_OP_MUL && m->src[0] == rms && c.idx(m) == i + 1) {
             const ggml_tensor * w = m->src[1];
             if (!is_f32(w) || w->ne[0] != rms->ne[0] || mi_nrows(w) != 1 || w->nb[0] != 4 || ((uintptr_t) w->data % 16)) return false;
-            if ((m->flags & GGML_TENSOR_FLAG_OUTPUT) || name_is_result(m)) return false;
+            if (wanted) return false;                                   // the bare norm is wanted but only norm * w would be written
+            wanted = (m->flags & GGML_TENSOR_FLAG_OUTPUT) || name_is_result(m);
             x = m;
         }
     }
@@ -213,6 +216,7 @@ static bool can_defer_norm(const gctx & c, int i) {
         if (!reads) continue;
         if (t->op != GGML_OP_MUL_MAT || t->src[1] != x || !mi_mul_mat_q_supported_type(t->src[0]->type) || t->src[0]->ne[2] != 1 || t->src[0]->ne[3] != 1) return false;
         if (!mi_supports_op(0, t)) return false;
+        if (wanted && !mi_ensure_tiled(t->src[0])) return false;
         found++; last = j;
     }
     if (found != nu) return false;

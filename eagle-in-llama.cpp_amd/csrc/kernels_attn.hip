@@ -18,6 +18,7 @@
 #include <hip/hip_fp16.h>
 #include "kernels.h"
 #include <mutex>
+#include <cstdlib>
 
 #define WAVE 64
 typedef int      i32x4 __attribute__((ext_vector_type(4)));
@@ -30,8 +31,20 @@ __device__ __forceinline__ float rnd16(float v) { return __half2float(__float2ha
 // LDS image: sc [tt][n_kv + 4] fp32 scores, ph [tt][n_kv + 8] f16 probabilities, red [4][64] float4 partial tiles
 static inline size_t attn_lds_bytes(int n_kv, int tt) { return (size_t) tt * (n_kv + 4) * 4 + (size_t) tt * (n_kv + 8) * 2 + 4 * 64 * 16 + 4 * 4 * 1024; }    // + per-wave V staging (row-major V only)
 
-template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_attn_args a, const int tt) {
+// diagnostic stamps (GGML_MI355X_ATTN_STAMPS, scripts/attn_stamps.py): the STAMP = true instantiation writes s_memrealtime at the phase
+// boundaries into a debug buffer nothing else reads; the product instantiation contains no stamp code
+__device__ unsigned long long * g_attn_stamps = nullptr;
+template <bool STAMP> __device__ __forceinline__ void attn_stamp(int idx) {
+    if constexpr (STAMP) {
+        if ((threadIdx.x & 63) == 0 && g_attn_stamps) {
+            const int blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            if (blk < 512) g_attn_stamps[((size_t) blk * 4 + (threadIdx.x >> 6)) * 8 + idx] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+}
+template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_attn_small(const mi_attn_args a, const int tt) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    attn_stamp<STAMP>(0);
     const int n_kv = a.n_kv;
     const int ldS = n_kv + 4, ldP = n_kv + 8;
     float    * sc  = (float *) lds;
@@ -62,21 +75,11 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
         else vf0[u] = (i < n_kv) ? *(const i32x4 *)(vb + (int64_t)(dd0 + col) * a.v_nb1 + (int64_t) i * 2) : (i32x4)(0);
     }
     // ---- phase 1: scores[cell][t] = K[cell][:] . q[t][:]      (A = 16 cells x 32 dims, B = 32 dims x 16 tokens)
-    f16x8 qf[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (col < nt) {
-            const float * qp = (const float *)((const char *) a.q + (int64_t)(t0 + col) * a.q_nb1 + (int64_t) h * a.q_nb2) + 32*s + 8*grp;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16) qp[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16) 0.f;
-        }
-    }
+    // Every global load of the phase -- the first K tiles, their mask values, the q rows -- is requested before anything is waited
+    // for (the kernel is a chain of latencies, not of bytes: serialising q -> K cost a full memory round trip).
     constexpr int CU = 4;                                  // cell tiles in flight per wave (CU*NS 16-byte loads per lane): n_kv <= 256 is one round trip
-    for (int c0 = wave*16; c0 < n_kv; c0 += 4*16*CU) {
-        i32x4 kf[CU][NS];
+    i32x4 kf[CU][NS]; f32x4 mk[CU];
+    auto load_k = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
             const int cell = c0 + u*64 + col;
@@ -84,7 +87,6 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
             for (int s = 0; s < NS; ++s) kf[u][s] = (cell < n_kv) ? *(const i32x4 *)(kb + (int64_t) cell * a.k_nb1 + (32*s + 8*grp) * 2) : (i32x4)(0);
         }
         // the mask values of the C elements this lane will own go out with the K loads (phase 2 then never touches global memory)
-        f32x4 mk[CU];
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
             const int r0 = c0 + u*64 + 4*grp;
@@ -95,6 +97,23 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
                 else mk[u] = *(const f32x4 *)(mrow + (int64_t) r0 * 4);
             }
         }
+    };
+    if (wave*16 < n_kv) load_k(wave*16);
+    f32x4 qr[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float * qp = (const float *)((const char *) a.q + (int64_t)(t0 + (col < nt ? col : 0)) * a.q_nb1 + (int64_t) h * a.q_nb2) + 32*s + 8*grp;
+        __builtin_memcpy(&qr[s][0], qp, 16); __builtin_memcpy(&qr[s][1], qp + 4, 16);      // rows are only known to be 4-byte aligned
+    }
+    attn_stamp<STAMP>(1);                                  // everything requested
+    f16x8 qf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[s][j] = col < nt ? (_Float16) qr[s][j >> 2][j & 3] : (_Float16) 0.f;
+    }
+    for (int c0 = wave*16; c0 < n_kv; c0 += 4*16*CU) {
+        if (c0 != wave*16) load_k(c0);
 #pragma unroll
         for (int u = 0; u < CU; ++u) {
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
@@ -108,26 +127,30 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
             }
         }
     }
+    attn_stamp<STAMP>(2);
     __syncthreads();
-    // ---- phase 2: soft-max, 16 lanes per token row, probabilities rounded to f16 (the vec_dot_type of the f16 V cache)
+    attn_stamp<STAMP>(3);
+    // ---- phase 2: soft-max, 256 / tt lanes per token row (32 for draft / verification batches), probabilities rounded to f16 (the
+    // vec_dot_type of the f16 V cache)
     {
-        const int t = threadIdx.x >> 4, sub = threadIdx.x & 15;
+        const int lg = 256 / tt;                            // 32 or 16: a power of two inside one wave
+        const int t = threadIdx.x / lg, sub = threadIdx.x % lg;
         if (t < nt) {
             float * row = sc + t*ldS;
             _Float16 * prow = ph + t*ldP;
             float mx = -INFINITY;
-            for (int i = sub; i < n_kv; i += 16) mx = fmaxf(mx, row[i]);
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+            for (int i = sub; i < n_kv; i += lg) mx = fmaxf(mx, row[i]);
+            for (int o = lg >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, lg));
             double sum = 0.0;
-            for (int i = sub; i < n_kv; i += 16) { const float e = (row[i] == -INFINITY) ? 0.0f : expf(row[i] - mx); row[i] = e; sum += (double) e; }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+            for (int i = sub; i < n_kv; i += lg) { const float e = (row[i] == -INFINITY) ? 0.0f : expf(row[i] - mx); row[i] = e; sum += (double) e; }
+            for (int o = lg >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, lg);
             const float inv = (float)(1.0 / sum);
-            for (int i = sub; i < n_kv; i += 16) prow[i] = (_Float16)(row[i] * inv);
+            for (int i = sub; i < n_kv; i += lg) prow[i] = (_Float16)(row[i] * inv);
         }
     }
+    attn_stamp<STAMP>(4);
     __syncthreads();
+    attn_stamp<STAMP>(5);
     // ---- phase 3: out[t][dd] = sum_i V^T[dd][i] * p[t][i]      (A = 16 head dims x 32 cells, B = 32 cells x 16 tokens)
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (!a.v_row) {
@@ -172,6 +195,7 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
         }
     }
     }
+    attn_stamp<STAMP>(6);
     if (wpt > 1) {
         if (part) red[wave*64 + lane] = acc;
         __syncthreads();
@@ -185,6 +209,24 @@ template <int D> __global__ void __launch_bounds__(256) k_attn_small(const mi_at
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const int tok = 4*grp + r; if (tok < nt) *(float *)((char *) a.out + (int64_t)(dd0 + col)*4 + (int64_t) h * a.o_nb1 + (int64_t)(t0 + tok) * a.o_nb2) = acc[r]; }
     }
+    attn_stamp<STAMP>(7);
+}
+static unsigned long long * g_attn_stamp_dev = nullptr;
+static bool attn_stamps_on() {
+    static const bool on = [] {
+        if (!getenv("GGML_MI355X_ATTN_STAMPS")) return false;
+        const size_t n = (size_t) 512 * 4 * 8 * 8;
+        HIP_CHECK(hipMalloc((void **) &g_attn_stamp_dev, n)); HIP_CHECK(hipMemset(g_attn_stamp_dev, 0, n));
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &g_attn_stamp_dev, sizeof(void *)));
+        return true;
+    }();
+    return on;
+}
+extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_attn_stamps(unsigned long long * out) {
+    if (!g_attn_stamp_dev) return 0;
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipMemcpy(out, g_attn_stamp_dev, (size_t) 512 * 4 * 8 * 8, hipMemcpyDeviceToHost));
+    return 512 * 4 * 8;
 }
 
 static int attn_tokens_per_block(const mi_attn_args & a) { return (a.T > 8 && attn_lds_bytes(a.n_kv, 16) <= 150*1024) ? 16 : 8; }
@@ -213,6 +255,11 @@ void mi_op_attn_small(hipStream_t st, const mi_attn_args & a) {
         HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
         HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
     });
+    if (a.d == 128 && attn_stamps_on()) {
+        static std::once_flag o2; std::call_once(o2, [] { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024)); });
+        k_attn_small<128, true><<<grid, 256, lds, st>>>(a, tt);
+        return;
+    }
     if (a.d == 128) k_attn_small<128><<<grid, 256, lds, st>>>(a, tt);
     else            k_attn_small<64><<<grid, 256, lds, st>>>(a, tt);
 }

@@ -186,6 +186,56 @@ __device__ __forceinline__ void mt_load_sb(const act_src & a, f32x4v (&x)[64/LG]
 #pragma unroll
     for (int i = 0; i < 64/LG; ++i) x[i] = *(const f32x4v *)(base + mt_eoff<Q80, LG>(i));
 }
+template <int TYPE, int LG, int NSB, class PFN>
+__device__ __forceinline__ void mt_norm_quant(const act_src & a, const int T, const int k, const int nun, const int nsb, const int ldq,
+                                              int8_t * lq, float * ldy, char * lrec, double * rd, const int lane, const int wave, PFN prefetch) {
+    constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
+    constexpr int NF = 64/LG;
+    const int t = lane / LG, p = lane % LG;
+    const bool tv = t < T;
+    f32x4v xv[NSB][NF], wv[NF];
+    double ss = 0.0;
+#pragma unroll
+    for (int c = 0; c < NSB; ++c) if (wave + 16*c < nun) mt_load_sb<TYPE, LG>(a, xv[c], tv, t, p, wave + 16*c);
+    if (NSB == 1 && a.norm_w && wave < nun) {
+        const float * wb = a.norm_w + wave*256 + mt_poff<Q80, LG>(p);
+#pragma unroll
+        for (int i = 0; i < NF; ++i) wv[i] = *(const f32x4v *)(wb + mt_eoff<Q80, LG>(i));
+    }
+    prefetch();
+#pragma unroll
+    for (int c = 0; c < NSB; ++c) {
+        if (wave + 16*c < nun) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) { const f32x4v q = xv[c][i] * xv[c][i]; ss += (double) q.x; ss += (double) q.y; ss += (double) q.z; ss += (double) q.w; }
+        }
+    }
+    ss = grp_sum_d<LG>(ss);
+    if (p == 0) rd[t*16 + wave] = ss;
+    __syncthreads();
+    // the 16 wave partials of this lane's token: spread over the first 16 / 8 lanes of the group, then the same group sum
+    double tot = 0.0;
+    if (LG >= 16) { if (p < 16) tot = rd[t*16 + p]; }
+    else tot = rd[t*16 + p] + rd[t*16 + p + 8];
+    tot = grp_sum_d<LG>(tot);
+    const float mean = (float)(tot / (double) k);
+    const float s1 = 1.0f / sqrtf(mean + a.eps);
+#pragma unroll
+    for (int c = 0; c < NSB; ++c) {
+        const int sb = wave + 16*c;
+        if (sb < nun) {
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int e = sb*256 + mt_poff<Q80, LG>(p) + mt_eoff<Q80, LG>(i);
+                f32x4v v = xv[c][i] * s1;
+                if (a.norm_w) v *= (NSB == 1) ? wv[i] : *(const f32x4v *)(a.norm_w + e);
+                if (a.norm_out && blockIdx.x == 0 && tv) *(f32x4v *)(a.norm_out + (size_t) t*a.norm_os + e) = v;
+                xv[c][i] = v;
+            }
+            mt_quant_sb<TYPE, LG>(xv[c], tv, t, p, sb, ldq, nsb, lq, ldy, lrec);
+        }
+    }
+}
 // `prefetch` issues the block's first weight-tile loads.  It runs right AFTER the first activation loads: vmcnt retires in issue order, so
 // activations requested behind the (HBM-cold) weight tiles would wait for them; this way the L2-warm activations come back first and
 // the quantiser's arithmetic overlaps the weight latency.
@@ -198,49 +248,10 @@ __device__ __forceinline__ void mt_quantise_lg(const act_src & a, const int T, c
     const bool tv = t < T;
     if (a.norm) {
         // ggml_compute_forward_rms_norm_f32 (R/ggml/src/ggml-cpu/ggml-cpu.c:7098-7144): sum of x*x (float products) in double,
-        // mean = (float)(sum / k), scale = 1/sqrtf(mean + eps); then MUL by the norm weight.  k <= 8192 here: two super-blocks per wave at most.
-        f32x4v xv[2][NF];
-        double ss = 0.0;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int sb = wave + 16*c;
-            if (sb < nun) {
-                mt_load_sb<TYPE, LG>(a, xv[c], tv, t, p, sb);
-            }
-        }
-        prefetch();
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (wave + 16*c < nun) {
-#pragma unroll
-                for (int i = 0; i < NF; ++i) { const f32x4v q = xv[c][i] * xv[c][i]; ss += (double) q.x; ss += (double) q.y; ss += (double) q.z; ss += (double) q.w; }
-            }
-        }
-        ss = grp_sum_d<LG>(ss);
-        if (p == 0) rd[t*16 + wave] = ss;
-        __syncthreads();
-        // the 16 wave partials of this lane's token: spread over the first 16 / 8 lanes of the group, then the same group sum
-        double tot = 0.0;
-        if (LG >= 16) { if (p < 16) tot = rd[t*16 + p]; }
-        else tot = rd[t*16 + p] + rd[t*16 + p + 8];
-        tot = grp_sum_d<LG>(tot);
-        const float mean = (float)(tot / (double) k);
-        const float s1 = 1.0f / sqrtf(mean + a.eps);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int sb = wave + 16*c;
-            if (sb < nun) {
-#pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    const int e = sb*256 + mt_poff<Q80, LG>(p) + mt_eoff<Q80, LG>(i);
-                    f32x4v v = xv[c][i] * s1;
-                    if (a.norm_w) v *= *(const f32x4v *)(a.norm_w + e);
-                    if (a.norm_out && blockIdx.x == 0 && tv) *(f32x4v *)(a.norm_out + (size_t) t*a.norm_os + e) = v;
-                    xv[c][i] = v;
-                }
-                mt_quant_sb<TYPE, LG>(xv[c], tv, t, p, sb, ldq, nsb, lq, ldy, lrec);
-            }
-        }
+        // mean = (float)(sum / k), scale = 1/sqrtf(mean + eps); then MUL by the norm weight.  k <= 8192 here: two super-blocks per wave at
+        // most; with one (k <= 4096, the usual case) the norm weights are requested together with the activations, ahead of the barrier.
+        if (nun <= 16) mt_norm_quant<TYPE, LG, 1>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch);
+        else           mt_norm_quant<TYPE, LG, 2>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch);
     } else {
         f32x4v x[NF];
         if (wave < nun) mt_load_sb<TYPE, LG>(a, x, tv, t, p, wave);

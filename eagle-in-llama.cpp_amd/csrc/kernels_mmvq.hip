@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(512) k_quant_q8K(const act_src a, int k, char 
             const float mean = (float)(tot / (double) k), sc = 1.0f / sqrtf(mean + a.eps);
             v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
             if (a.norm_w) { const float4 w = *(const float4 *)(a.norm_w + sb*256 + lane*4); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+            if (a.norm_out) *(float4 *)(a.norm_out + (size_t) t*a.norm_os + sb*256 + lane*4) = v;
         } else {
             const int e = sb*256 + lane*4;
             v = (a.X2 && e >= a.ksplit) ? *(const float4 *)(a.X2 + (size_t) t*a.xs2 + (e - a.ksplit)) : *(const float4 *)(row + e);
@@ -417,6 +418,7 @@ void mi_quant_act(hipStream_t st, int type, int T, const act_src & a0, int k, ch
     for (int t0 = 0; t0 < T; t0 += 8) {                       // images of more than 8 tokens (matrix-core kernel) are filled 8 tokens per launch
         act_src a = a0; a.X += (size_t) t0 * a.xs;
         if (a.X2) a.X2 += (size_t) t0 * a.xs2;                 // the second CONCAT source advances with the tokens too
+        if (a.norm_out) a.norm_out += (size_t) t0 * a.norm_os;
         const int n = T - t0 < 8 ? T - t0 : 8;
         if (mi_traits(type).blck == 256) quant_act_T<true>(st, n, a, k, out, T, t0); else quant_act_T<false>(st, n, a, k, out, T, t0);
     }

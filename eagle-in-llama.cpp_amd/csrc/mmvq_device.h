@@ -93,6 +93,7 @@ __device__ __forceinline__ float4 fetch4(const act_src & a, const float * sc, in
         const float s = sc[t];
         v.x *= s; v.y *= s; v.z *= s; v.w *= s;
         if (a.norm_w) { const float4 w = *(const float4 *)(a.norm_w + e); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+        if (a.norm_out) *(float4 *)(a.norm_out + (size_t) t*a.norm_os + e) = v;      // quantiser launches only (kernels_mmt.hip): the folded norm is materialised
     }
     return v;
 }
