@@ -68,14 +68,15 @@ def pmc_traffic():
 def cpu_baseline(ea, cfg, ftype):
     """The reference's own ggml CPU backend (oracle/_ref, built from /root/reference) running the SAME driver on a
     bounded sample of the same workload.  Falls back to nothing (null) when oracle/_ref is absent."""
-    if not os.path.exists(ea.REF_GGML_PATH):
+    import refapi                                                  # tests/refapi.py: the only place that knows oracle/_ref
+    if not os.path.exists(refapi.REF_GGML_PATH):
         return None
     try:
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 4
     threads = max(1, min(threads, 32))
-    be = ea.Backend.reference_cpu(threads=threads)
+    be = refapi.reference_cpu(ea, threads=threads)
     t0 = time.time()
     tgt = ea.Model(be, cfg, ftype, n_ctx=256, seed=42)
     dft = ea.Model(be, cfg, ftype, n_ctx=256, eagle_of=tgt, seed=42, accept_p=0.8)

@@ -21,9 +21,6 @@ ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "lib")
 PLUGIN_PATH = os.path.join(LIB, "libggml-mi355x.so")
 HOST_PATH = os.path.join(LIB, "libeagle_host.so")
-REF_DIR = os.path.join(ROOT, "oracle", "_ref")
-REF_GGML_PATH = os.path.join(REF_DIR, "libggml-ref.so")
-REF_GGML_SCALAR_PATH = os.path.join(REF_DIR, "libggml-ref-scalar.so")
 
 # ggml enums (include/ggml_abi.h)
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, I32, BF16 = 0, 1, 2, 8, 12, 13, 14, 26, 30
@@ -87,7 +84,8 @@ def host():
 
 
 class Backend:
-    """A loaded ggml-ABI backend: our plugin (`Backend.mi355x()`) or the reference CPU backend (`Backend.reference_cpu()`)."""
+    """A loaded ggml-ABI backend.  The product only ever loads our plugin (`Backend.mi355x()`); the tests load the reference CPU
+    backend through the same class (tests/refapi.py: `reference_cpu`) -- nothing in this package knows where oracle/ lives."""
 
     def __init__(self, path, entry, device=0, threads=None):
         err = C.create_string_buffer(512)
@@ -101,19 +99,6 @@ class Backend:
     @staticmethod
     def mi355x(device=0):
         return Backend(require_plugin(), "ggml_backend_init", device)
-
-    @staticmethod
-    def reference_cpu(threads=None, scalar=False):
-        p = REF_GGML_SCALAR_PATH if scalar else REF_GGML_PATH
-        if not os.path.exists(p):
-            raise FileNotFoundError(f"{p} not built (make -C oracle ref; needs /root/reference)")
-        if threads is None:      # cores this process may actually use (a GPU box exposes many more than its share), capped
-            try:
-                threads = len(os.sched_getaffinity(0))
-            except AttributeError:
-                threads = os.cpu_count() or 4
-            threads = max(1, min(threads, 16))
-        return Backend(p, "ggml_backend_cpu_reg", 0, threads)
 
     @property
     def name(self):
@@ -288,6 +273,7 @@ def _model_sigs():
         "eh_spec_run": (i32, [vp, vp, i32p, i32, i32, i32, f32, i32p, f64p]),
         "eh_spec_begin": (vp, [vp, vp, i32p, i32]), "eh_spec_rounds": (i32, [vp, i32, i32, f32, i32p, i32, f64p]), "eh_spec_end": (None, [vp]),
         "eh_plain_run": (i32, [vp, i32p, i32, i32, i32p, f64p]),
+        "eh_tree_begin": (vp, [vp, vp, i32p, i32, i32p, C.POINTER(C.c_float)]), "eh_tree_run": (i32, [vp, i32, i32, i32p, i32, f64p]), "eh_tree_end": (None, [vp]),
         "eh_spec_draft": (i32, [vp, i32, f32, i32p, f64p]), "eh_spec_verify": (i32, [vp, i32p, f64p]), "eh_spec_state": (None, [vp, i32p, i32p]),
     }
     for name, (res, args) in sig.items():
@@ -412,4 +398,37 @@ class SpecSession:
     def close(self):
         if self.h:
             _model_sigs().eh_spec_end(self.h)
+            self.h = None
+
+
+TREE_STAT_NAMES = ["n_predict", "n_drafted", "n_accept", "n_iters", "n_forks", "max_batch", "t_us", "t_draft_us", "t_verify_us", "n_draft_calls"]
+
+
+class TreeSession:
+    """Tree speculative decoding (host/tree_driver.cpp, mirror of R/examples/speculative/speculative-eagle.cpp): up to `n_seq_dft` branches,
+    a branch forks while a further candidate has probability > `p_split`; `temp` = 0 verifies greedily, `temp_dft` shapes the draft's
+    candidate distribution (defaults to `temp`; 0 = one-hot = a chain)."""
+
+    def __init__(self, target, draft, prompt, n_seq_dft=4, n_draft=5, p_split=0.1, temp=0.0, temp_dft=None, top_k=40, seed=1234):
+        h = _model_sigs()
+        pr = (C.c_int32 * len(prompt))(*prompt)
+        ip = (C.c_int32 * 4)(n_seq_dft, n_draft, top_k, seed)
+        fp = (C.c_float * 3)(p_split, temp, temp if temp_dft is None else temp_dft)
+        self.n_draft, self.n_seq_dft = n_draft, n_seq_dft
+        self.h = h.eh_tree_begin(target.h, draft.h, pr, len(prompt), ip, fp)
+        if not self.h:
+            raise RuntimeError("tree driver: prompt processing failed")
+
+    def run(self, n_predict, max_rounds=1 << 30):
+        h = _model_sigs()
+        cap = n_predict + self.n_draft + 8
+        out = (C.c_int32 * cap)(); st = (C.c_double * 16)()
+        k = h.eh_tree_run(self.h, n_predict, max_rounds, out, cap, st)
+        if k < 0:
+            raise RuntimeError(f"eh_tree_run returned {k}")
+        return list(out[:k]), {nm: st[i] for i, nm in enumerate(TREE_STAT_NAMES)}
+
+    def close(self):
+        if self.h:
+            _model_sigs().eh_tree_end(self.h)
             self.h = None

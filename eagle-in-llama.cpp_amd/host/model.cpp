@@ -406,13 +406,15 @@ int Model::decode(const Batch & b, bool want_hidden) {
     if (T <= 0) return -1;
     if (cfg.eagle && (int) b.hidd.size() != T * cfg.n_embd) return -2;
     for (int i = 0; i < T; ++i) if (b.token[i] < 0 || b.token[i] >= cfg.n_vocab) return -6;       // llama_decode: "invalid token" (R/src/llama.cpp:9500)
+    // cells claimed by find_slot are given back when the decode fails (llama_kv_slot_restorer, R/src/llama.cpp:9518-9546)
+    const KVCache kv_saved = kv;
     if (!kv.find_slot(b)) return 1;
     const uint32_t pad = 32;                                 // llama_kv_cache_get_padding without flash-attn
     kv.n = std::min(kv.size, std::max(pad, (kv.cell_max() + pad - 1) / pad * pad));
     const int n_kv = (int) kv.n, kv_head = (int) kv.head;
     static const bool force_tp = getenv("EH_FORCE_TP") != nullptr;     // run the segmented path + collectives even with one rank (single-GPU rehearsal)
     const bool tp = cfg.tp_size > 1 || (force_tp && allreduce && !cfg.eagle);
-    if (tp && !allreduce) return -5;
+    if (tp && !allreduce) { kv = kv_saved; return -5; }
     const int E = cfg.n_embd;
     std::vector<Cut> cuts;                                   // tensor parallel: partial sums to all-reduce, and where the graph is cut
     n_outputs = 0; out_ids.clear();
@@ -434,7 +436,7 @@ int Model::decode(const Batch & b, bool want_hidden) {
     build_forward(g, io, tp, &cuts, result_norm, result_output, result_argmax);
     const bool head_here = !tp || cfg.tp_rank == 0;          // TP: the LM head (and the hidden-state channel) live on rank 0
     last_n_nodes = (int) g.nodes.size();
-    if (!g.alloc()) return -3;
+    if (!g.alloc()) { kv = kv_saved; return -3; }
     const double t1 = now_us();
 
     // ---- inputs (llama_set_inputs, R/src/llama-context.cpp:61-210).  The input tensors were created first, so they sit
@@ -504,7 +506,7 @@ int Model::decode(const Batch & b, bool want_hidden) {
     be->synchronize();
     const double t3 = now_us();
     g.t_issue_us += t3a - t2; g.t_wait_us += t3 - t3a;
-    if (st != GGML_STATUS_SUCCESS) { return st == GGML_STATUS_ABORTED ? 2 : -4; }
+    if (st != GGML_STATUS_SUCCESS) { kv = kv_saved; return st == GGML_STATUS_ABORTED ? 2 : -4; }
     argmax_ids.clear();
     if (head_here && result_argmax) { const int32_t * p = (const int32_t *) ids_stage.data(); argmax_ids.assign(p, p + n_outputs); }
     kv.head += T;

@@ -2,8 +2,9 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from conftest import load_package
 import numpy as np
+import refapi
 ea = load_package()
-gpu = ea.Backend.mi355x(0); cpu = ea.Backend.reference_cpu(threads=8)
+gpu = ea.Backend.mi355x(0); cpu = refapi.reference_cpu(ea, threads=8)
 rng = np.random.default_rng(5)
 def rel(a, b): return float(np.abs(a.astype(np.float64)-b.astype(np.float64)).max()/(np.abs(b).max()+1e-30))
 for (T, n_kv, H, Hkv, D) in [(16, 32, 4, 4, 64), (16, 32, 8, 2, 64), (6, 96, 4, 2, 64), (16, 160, 32, 32, 128)]:

@@ -1,10 +1,11 @@
 import sys, os, time; sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from conftest import load_package
 import numpy as np
+import refapi
 ea = load_package()
 which = sys.argv[1] if len(sys.argv) > 1 else "gpu"
 cfgname = sys.argv[2] if len(sys.argv) > 2 else "tiny"
-be = ea.Backend.mi355x(0) if which == "gpu" else ea.Backend.reference_cpu(threads=8)
+be = ea.Backend.mi355x(0) if which == "gpu" else refapi.reference_cpu(ea, threads=8)
 tgt = ea.Model(be, cfgname, "q4_k_m", n_ctx=512, seed=42)
 dft = ea.Model(be, cfgname, "q4_k_m", n_ctx=512, eagle_of=tgt, seed=42, accept_p=0.8)
 V = tgt.n_vocab

@@ -45,11 +45,13 @@ def have_ref():
 def ref_cpu(ea):
     if not have_ref():
         pytest.skip("oracle/_ref not built (needs /root/reference in the build container)")
-    return ea.Backend.reference_cpu()
+    import refapi
+    return refapi.reference_cpu(ea)
 
 
 @pytest.fixture(scope="session")
 def ref_scalar(ea):
     if not have_ref():
         pytest.skip("oracle/_ref not built")
-    return ea.Backend.reference_cpu(scalar=True)
+    import refapi
+    return refapi.reference_cpu(ea, scalar=True)

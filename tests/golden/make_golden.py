@@ -29,7 +29,7 @@ def run_mul_mat(be, t, w, x, k, rows):
 
 
 def main():
-    scalar, avx2 = ea.Backend.reference_cpu(scalar=True, threads=4), ea.Backend.reference_cpu(threads=4)
+    scalar, avx2 = refapi.reference_cpu(ea, scalar=True, threads=4), refapi.reference_cpu(ea, threads=4)
     rng = np.random.default_rng(20251004)
     k, rows, T = 512, 64, 8
     for name, t in QTYPES.items():

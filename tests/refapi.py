@@ -8,6 +8,24 @@ REF = os.path.join(ROOT, "oracle", "_ref")
 F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K = 0, 1, 2, 8, 12, 13, 14
 BLOCK = {Q4_0: (32, 18), Q8_0: (32, 34), Q4_K: (256, 144), Q5_K: (256, 176), Q6_K: (256, 210)}
 _libs = {}
+REF_GGML_PATH = os.path.join(REF, "libggml-ref.so")
+REF_GGML_SCALAR_PATH = os.path.join(REF, "libggml-ref-scalar.so")
+
+
+def reference_cpu(ea, threads=None, scalar=False):
+    """The reference's own ggml CPU backend (oracle/_ref, built from /root/reference by oracle/Makefile) loaded through the same host ABI
+    as the plugin.  Checker / CPU baseline only: tests, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+    p = REF_GGML_SCALAR_PATH if scalar else REF_GGML_PATH
+    if not os.path.exists(p):
+        raise FileNotFoundError(f"{p} not built (make -C oracle ref; needs /root/reference)")
+    if threads is None:      # cores this process may actually use (a GPU box exposes many more than its share), capped
+        try:
+            threads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            threads = os.cpu_count() or 4
+        threads = max(1, min(threads, 16))
+    return ea.Backend(p, "ggml_backend_cpu_reg", 0, threads)
+
 
 
 def lib(scalar=True):

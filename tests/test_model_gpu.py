@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import have_ref
+import refapi
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")]
 
@@ -75,7 +76,7 @@ def test_reference_builds_disagree_alike(ea):
     """calibration of the tolerance above: the reference's AVX2 build against its own scalar build, same graphs"""
     outs = []
     for scalar in (False, True):
-        be = ea.Backend.reference_cpu(threads=4, scalar=scalar)
+        be = refapi.reference_cpu(ea, threads=4, scalar=scalar)
         m = ea.Model(be, "tiny", "q8_0", n_ctx=256, seed=3, predictable=False)
         lg, hid = m.decode(list(range(5, 21)), list(range(16)))
         outs.append(lg); m.close()
@@ -131,3 +132,47 @@ def test_long_generation_stays_lossless(ea, gpu):
     assert plain == spec[:len(plain)]
     assert st["n_accept"] > 100
     d.close(); t.close()
+
+
+@pytest.mark.parametrize("ftype", ["q4_k_m", "q8_0"])
+def test_speculative_tokens_identical_when_layers_matter(ea, gpu, ref_cpu, ftype, monkeypatch):
+    """Same comparison on a model whose residual branches carry 5 % of the stream (EH_TINY = 0.05 instead of 1e-4: wo and ffn_down
+    are no longer numerically inert), so attention, the tree mask, soft-max and the FFN can move the arg-max.  Chain and tree driver."""
+    monkeypatch.setenv("EH_TINY", "0.05")
+    seqs, trees = [], []
+    for be in (gpu, ref_cpu):
+        t = ea.Model(be, "tiny", ftype, n_ctx=512, seed=23)
+        d = ea.Model(be, "tiny", ftype, n_ctx=512, eagle_of=t, seed=23, accept_p=0.75)
+        prompt = [int(x) for x in np.random.default_rng(4321).integers(5, 512, 32)]
+        plain, _ = ea.plain_generate(t, prompt, 64)
+        spec, st = ea.spec_generate(t, d, prompt, 64, n_draft=5)
+        assert plain == spec[:len(plain)]
+        seqs.append((spec, st["n_accept"], st["n_drafted"], st["n_iters"]))
+        s = ea.TreeSession(t, d, prompt, n_seq_dft=4, n_draft=6, p_split=0.02, temp=0.0, temp_dft=1.5, top_k=8)
+        toks, ts = s.run(64); s.close()
+        assert toks[:64] == plain[:64]
+        trees.append((toks, ts["n_accept"], ts["n_forks"], ts["n_drafted"], ts["max_batch"]))
+        d.close(); t.close()
+    assert seqs[0] == seqs[1] and seqs[0][1] > 0
+    assert trees[0] == trees[1] and trees[0][2] > 0
+
+
+def test_tree_driver_identical_to_reference_cpu(ea, gpu, ref_cpu):
+    """the tree driver (forks on p_split, seq_cp, multi-branch greedy acceptance, KV fix-up) on the plugin and on the reference CPU
+    backend: same tokens, same accepted / forked / drafted counts; a wide tree (10 branches, 60 drafts: BASELINE config 3's shape)
+    sends > 60 tokens through one verification batch"""
+    for kw in (dict(n_seq_dft=4, n_draft=6, p_split=0.02, temp=0.0, temp_dft=1.5, top_k=8), dict(n_seq_dft=10, n_draft=60, p_split=0.01, temp=0.0, temp_dft=2.0, top_k=12)):
+        res = []
+        for be in (gpu, ref_cpu):
+            t = ea.Model(be, "tiny", "q4_k_m", n_ctx=1024, seed=5)
+            d = ea.Model(be, "tiny", "q4_k_m", n_ctx=1024, eagle_of=t, seed=5, accept_p=0.7)
+            prompt = [int(x) for x in np.random.default_rng(3).integers(5, 512, 16)]
+            plain, _ = ea.plain_generate(t, prompt, 64)
+            s = ea.TreeSession(t, d, prompt, **kw)
+            toks, st = s.run(64); s.close()
+            assert toks[:64] == plain[:64]
+            res.append((toks, st["n_accept"], st["n_forks"], st["n_drafted"], st["max_batch"]))
+            d.close(); t.close()
+        assert res[0] == res[1], kw
+        assert res[0][2] > 0
+    assert res[0][4] > 60

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import have_ref, ROOT
+import refapi
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")
 
@@ -20,7 +21,7 @@ def test_tp_matches_unsharded(ea, tmp_path, world):
     for p in procs:
         assert p.wait(timeout=300) == 0
     z = np.load(out)
-    be = ea.Backend.reference_cpu(threads=2)
+    be = refapi.reference_cpu(ea, threads=2)
     m = ea.Model(be, "tiny-gqa", "q4_k_m", n_ctx=128, seed=9, predictable=False)
     lg, hid = m.decode(list(range(7, 19)), list(range(12)))
     lg1, hid1 = m.decode([40, 41, 42], [12, 13, 13], seq=[0, 0, 0])

@@ -4,6 +4,7 @@ import os, sys, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from conftest import load_package
+import refapi
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
@@ -11,7 +12,7 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ea = load_package()
-    be = ea.Backend.reference_cpu(threads=2)
+    be = refapi.reference_cpu(ea, threads=2)
     m = ea.Model(be, "tiny-gqa", "q4_k_m", n_ctx=128, seed=9, predictable=False, tp_rank=rank, tp_size=world)
     def allreduce(ptr, n):
         buf = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), (n,))
