@@ -59,7 +59,7 @@ def host():
             "eh_backend_free": (None, [vp]), "eh_backend_name": (C.c_char_p, [vp]),
             "eh_backend_description": (C.c_char_p, [vp]),
             "eh_backend_set_threads": (None, [vp, i32]), "eh_backend_is_host": (i32, [vp]),
-            "eh_ctx_new": (vp, [vp, i32]), "eh_ctx_free": (None, [vp]),
+            "eh_ctx_new": (vp, [vp, i32]), "eh_ctx_free": (None, [vp]), "eh_ctx_use_split": (i32, [vp, i32, C.POINTER(C.c_float)]),
             "eh_tensor_new": (vp, [vp, i32, i64, i64, i64, i64]),
             "eh_tensor_set_name": (None, [vp, vp, C.c_char_p]), "eh_tensor_set_flags": (None, [vp, i32]),
             "eh_view": (vp, [vp, vp, i32, C.POINTER(i64), C.POINTER(i64), i64]),
@@ -112,10 +112,17 @@ class Backend:
 class Graph:
     """One graph on one backend: create tensors/ops, `alloc()`, `set()`, `compute()`, `get()`."""
 
-    def __init__(self, backend, usage=USAGE_ANY):
+    def __init__(self, backend, usage=USAGE_ANY, split=None):
+        """split = (main_device, [proportion per device] or None): tensors of this graph context are allocated in the backend's row-split
+        buffer type, looked up the way the reference does for -sm row (get_proc_address("ggml_backend_split_buffer_type"))"""
         self.be = backend
         self.h = host().eh_ctx_new(backend.h, usage)
         self._keep = []
+        if split is not None:
+            main, props = split
+            arr = (C.c_float * 16)(*(list(props) + [0.0] * (16 - len(props)))) if props else None
+            if not host().eh_ctx_use_split(self.h, main, arr):
+                raise RuntimeError("backend offers no row-split buffer type")
 
     def __del__(self):
         try:

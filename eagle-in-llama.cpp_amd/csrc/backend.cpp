@@ -40,6 +40,10 @@ static ggml_backend_reg          g_reg;
 static ggml_guid                 g_guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x2d, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x2d, 0x30, 0x31 };
 
 static void set_device(int dev) { HIP_CHECK(hipSetDevice(dev)); }
+// for split.cpp (row-split buffers live outside the per-device buffer types)
+ggml_backend_buffer_t mi_make_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * ctx, size_t size) { return make_buffer(buft, iface, ctx, size); }
+int mi_device_count() { return g_ndev; }
+ggml_backend_dev_t mi_device(int i) { return (i >= 0 && i < g_ndev) ? &g_devs[i] : nullptr; }
 
 // ============================================================ weight re-layout state (tile_layout.h, kernels_tile.hip)
 // A quantised weight matrix keeps ggml's row-major blocks until the first MUL_MAT that reads it; mi_ensure_tiled() then permutes
@@ -323,7 +327,7 @@ static ggml_backend_buffer_type_t dev_host_buft(ggml_backend_dev_t) { return &g_
 static bool dev_supports_op(ggml_backend_dev_t d, const ggml_tensor * op) { return mi_supports_op(((mi_device_ctx *) d->context)->device, op); }
 static bool dev_supports_buft(ggml_backend_dev_t d, ggml_backend_buffer_type_t t) {
     // buffers of this device, usable from any backend instance (target and draft contexts share weights)
-    return mi_buft_is_ours(t) && t->device == d;
+    return (mi_buft_is_ours(t) || mi_buft_is_split(t)) && t->device == d;
 }
 static bool dev_offload_op(ggml_backend_dev_t, const ggml_tensor * op) {
     const int min_batch = 32;                                          // same threshold as the reference :3250-3256

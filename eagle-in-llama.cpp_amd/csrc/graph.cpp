@@ -47,6 +47,8 @@ bool mi_flash_attn_args(const ggml_tensor * op, mi_attn_args & a) {
 
 bool mi_supports_op(int, const ggml_tensor * op) {
     const ggml_tensor * a = op->src[0], * b = op->src[1];
+    // a row-split weight (split.cpp) exists only as per-device slices: nothing but MUL_MAT may read it, and only as src0 (reference: ggml-cuda.cu:2958-2966)
+    for (int s = 0; s < GGML_MAX_SRC; ++s) if (op->src[s] && mi_tensor_is_split(op->src[s])) return op->op == GGML_OP_MUL_MAT && s == 0 && mi_split_supports_mul_mat(op);
     switch (op->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             return true;
@@ -215,7 +217,7 @@ static bool can_defer_norm(const gctx & c, int i) {
         for (int s = 0; s < GGML_MAX_SRC; ++s) if (t->src[s] == x) reads = true;
         if (!reads) continue;
         if (t->op != GGML_OP_MUL_MAT || t->src[1] != x || !mi_mul_mat_q_supported_type(t->src[0]->type) || t->src[0]->ne[2] != 1 || t->src[0]->ne[3] != 1) return false;
-        if (!mi_supports_op(0, t)) return false;
+        if (!mi_supports_op(0, t) || mi_tensor_is_split(t->src[0])) return false;      // split weights run on several devices: they need the materialised tensor
         if (wanted && !mi_ensure_tiled(t->src[0])) return false;
         found++; last = j;
     }
@@ -238,7 +240,7 @@ static bool can_defer_concat(const gctx & c, int i) {
     if ((a->ne[0] % 4) || (a->nb[1] % 16) || (b->nb[1] % 16) || ((uintptr_t) a->data % 16) || ((uintptr_t) b->data % 16)) return false;
     const ggml_tensor * t = c.g->nodes[i + 1];
     if (t->op != GGML_OP_MUL_MAT || t->src[1] != x || !mi_mul_mat_q_supported_type(t->src[0]->type) || t->src[0]->ne[2] != 1 || t->src[0]->ne[3] != 1) return false;
-    if (x->ne[2] != 1 || x->ne[3] != 1 || !mi_supports_op(0, t)) return false;
+    if (x->ne[2] != 1 || x->ne[3] != 1 || !mi_supports_op(0, t) || mi_tensor_is_split(t->src[0])) return false;
     return true;
 }
 
@@ -492,6 +494,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
                 }
             } break;
             case GGML_OP_MUL_MAT: {
+                if (mi_tensor_is_split(t->src[0])) { mi_split_mul_mat(ctx, t); break; }                 // -sm row: slices on every device, gathered here
                 if (mi_mul_mat_q_supported_type(t->src[0]->type)) {
                     if (t->src[0]->view_src && mi_is_tiled(t->src[0]->view_src)) mi_untile(t->src[0], true);      // a view into a re-laid-out weight: back to ggml's layout for good
                     if (!run_mmvq_group(ctx, c, i, fuse)) mi_op_mul_mat_q(st, t, nullptr, t, ctx->act_cache);

@@ -104,6 +104,15 @@ bool mi_buft_is_ours(ggml_backend_buffer_type_t buft);
 bool mi_buft_is_our_host(ggml_backend_buffer_type_t buft);
 void * mi_scratch(mi_backend_ctx * ctx, size_t size);       // grow-only scratch on ctx->device
 
+// row-split weight buffers (split.cpp)
+ggml_backend_buffer_t mi_make_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * ctx, size_t size);
+int  mi_device_count();
+ggml_backend_dev_t mi_device(int i);
+bool mi_buft_is_split(ggml_backend_buffer_type_t buft);
+bool mi_tensor_is_split(const ggml_tensor * t);
+bool mi_split_supports_mul_mat(const ggml_tensor * op);
+void mi_split_mul_mat(mi_backend_ctx * ctx, const ggml_tensor * dst);          // dst = MUL_MAT(split weight, f32 activations), gathered on ctx's device
+
 // weight re-layout (backend.cpp / kernels_tile.hip / tile_layout.h)
 bool mi_is_tiled(const ggml_tensor * t);                    // t itself carries the tiled tag
 bool mi_tile_eligible(const ggml_tensor * w);

@@ -22,6 +22,7 @@ EH_API int eh_backend_is_host(void * b) { return ((Backend *) b)->is_host; }
 EH_API const char * eh_backend_description(void * b) { Backend * be = (Backend *) b; return be->dev->iface.get_description(be->dev); }
 EH_API void eh_backend_memory(void * b, size_t * fr, size_t * tot) { Backend * be = (Backend *) b; be->dev->iface.get_memory(be->dev, fr, tot); }
 
+EH_API int eh_ctx_use_split(void * c, int main_device, const float * tensor_split) { return ((Ctx *) c)->use_split(main_device, tensor_split) ? 1 : 0; }
 EH_API void * eh_ctx_new(void * be, int usage) { Ctx * c = new Ctx((Backend *) be); c->usage = usage; return c; }
 EH_API void eh_ctx_free(void * c) { delete (Ctx *) c; }
 EH_API void * eh_tensor_new(void * c, int type, int64_t ne0, int64_t ne1, int64_t ne2, int64_t ne3) { return ((Ctx *) c)->new_tensor(type, ne0, ne1, ne2, ne3); }

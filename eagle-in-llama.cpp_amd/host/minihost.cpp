@@ -203,10 +203,19 @@ ggml_tensor * Ctx::soft_max_ext(ggml_tensor * a, ggml_tensor * mask, float scale
     return r;
 }
 
+bool Ctx::use_split(int main_device, const float * tensor_split) {
+    if (!be->reg->iface.get_proc_address) return false;
+    typedef ggml_backend_buffer_type_t (*fn_t)(int, const float *);
+    fn_t fn = (fn_t) be->reg->iface.get_proc_address(be->reg, "ggml_backend_split_buffer_type");
+    if (!fn) return false;
+    buft_override = fn(main_device, tensor_split);
+    return buft_override != nullptr;
+}
 bool Ctx::alloc() {
-    const size_t align = be->buft->iface.get_alignment(be->buft);
+    ggml_backend_buffer_type_t bt = buft_override ? buft_override : be->buft;
+    const size_t align = bt->iface.get_alignment(bt);
     auto asize = [&](const ggml_tensor * t) -> size_t {
-        size_t s = be->buft->iface.get_alloc_size ? be->buft->iface.get_alloc_size(be->buft, t) : nbytes(t);
+        size_t s = bt->iface.get_alloc_size ? bt->iface.get_alloc_size(bt, t) : nbytes(t);
         return (s + align - 1) / align * align;
     };
     size_t total = 0;
@@ -217,7 +226,8 @@ bool Ctx::alloc() {
         else {
             if (reuse && !buffers.empty()) { be->synchronize(); be->free_buffer(buffers.back()); buffers.pop_back(); }
             const size_t cap = reuse ? total + total/4 + (1u << 20) : total;
-            buf = be->alloc_buffer(cap, usage);
+            if (buft_override) { buf = bt->iface.alloc_buffer(bt, cap); if (buf) buf->usage = (enum ggml_backend_buffer_usage) usage; }
+            else buf = be->alloc_buffer(cap, usage);
             if (!buf) return false;
             buffers.push_back(buf);
             if (reuse) reuse_cap = cap;

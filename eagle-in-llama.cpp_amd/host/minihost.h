@@ -83,6 +83,9 @@ struct Ctx {
     std::vector<ggml_backend_buffer_t> buffers;  // owned
     std::vector<ggml_tensor **> node_ptrs_storage;
     int usage = GGML_BACKEND_BUFFER_USAGE_ANY;
+    ggml_backend_buffer_type_t buft_override = nullptr;      // e.g. the row-split buffer type (-sm row): tensors of this Ctx are allocated there
+    // R/src/llama-model.cpp:310-322: ask the registry for "ggml_backend_split_buffer_type" and use what it returns for the weights
+    bool use_split(int main_device, const float * tensor_split);
 
     explicit Ctx(Backend * b) : be(b) {}
     ~Ctx();
