@@ -193,6 +193,7 @@ static bool can_defer_norm(const gctx & c, int i) {
     const ggml_tensor * rms = c.g->nodes[i];
     const ggml_tensor * a = rms->src[0];
     if (!is_f32(a) || a->nb[0] != 4 || a->ne[2] != 1 || a->ne[3] != 1 || (a->nb[1] % 16) || ((uintptr_t) a->data % 16)) return false;
+    if (a->ne[1] > 24) return false;                                   // big batches: the norm runs on its own, the mat-muls take the one-pass kernel
     // a norm the host will read back (graph output, "result_norm": the hidden-state channel) can still be folded when every reader is a
     // TILED launch: those write the normalised tensor as a side effect (kernels_mmt.hip, k_quant_q8K)
     bool wanted = (rms->flags & GGML_TENSOR_FLAG_OUTPUT) || name_is_result(rms);
@@ -234,7 +235,7 @@ static bool can_defer_norm(const gctx & c, int i) {
 // reads the two halves in place.  Nothing runs between the two nodes, so a and b are still intact when the mat-vec starts.
 static bool can_defer_concat(const gctx & c, int i) {
     const ggml_tensor * x = c.g->nodes[i];
-    if (mi_op_i32(x, 0) != 0 || c.n_uses(x) != 1 || (x->flags & GGML_TENSOR_FLAG_OUTPUT) || i + 1 >= c.n) return false;
+    if (mi_op_i32(x, 0) != 0 || c.n_uses(x) != 1 || (x->flags & GGML_TENSOR_FLAG_OUTPUT) || i + 1 >= c.n || x->ne[1] > 24) return false;
     const ggml_tensor * a = x->src[0], * b = x->src[1];
     if (!is_f32(a) || !is_f32(b) || a->nb[0] != 4 || b->nb[0] != 4 || a->ne[1] != b->ne[1] || a->ne[2] != 1 || a->ne[3] != 1 || b->ne[2] != 1 || b->ne[3] != 1) return false;
     if ((a->ne[0] % 4) || (a->nb[1] % 16) || (b->nb[1] % 16) || ((uintptr_t) a->data % 16) || ((uintptr_t) b->data % 16)) return false;
@@ -326,7 +327,10 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
     const ggml_tensor * w0 = t->src[0], * x = t->src[1];
     hipStream_t st = ctx->stream;
     const bool simple2d = w0->ne[2] == 1 && w0->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1;
-    if (!fuse || !simple2d) {
+    // more than 24 tokens (prompts, wide tree verification): every matrix runs on its own through the one-pass big-batch kernel
+    // (kernels_mmt.hip, k_mmt_ts: weights streamed once for up to 128 tokens); only the residual ADD is still folded in
+    const bool big = x->ne[1] > 24;
+    if (!fuse || !simple2d || big) {
         // RMS_NORM deferred to us?  only possible when fuse is on, so nothing to undo here
         const ggml_tensor * res = nullptr; ggml_tensor * nx = (i + 1 < c.n) ? c.g->nodes[i + 1] : nullptr;
         if (fuse && nx && nx->op == GGML_OP_ADD && c.n_uses(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT) && is_f32(nx) && nx->nb[0] == 4 && mi_same_shape(nx, t)) {

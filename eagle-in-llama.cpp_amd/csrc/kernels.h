@@ -38,6 +38,8 @@ struct mmvq_launch { act_src act; int k; int n_mat; int swiglu; mmvq_mat m[3]; m
 struct mi_act_cache {                  // quantised-activation images in HBM scratch (see mi_mmvq_run)
     char * pool = nullptr; size_t slot_bytes = 0; int next = 0; uint64_t epoch = 0;
     struct entry { const void * key; uint64_t epoch; int t0, T, kq, k; } e[MI_ACT_SLOTS] = {};
+    // whole-batch images of the big-batch kernel (k_mmt_bb): 4 x 8 MiB, allocated at first use
+    char * big_pool = nullptr; int big_next = 0; entry big[4] = {};
 };
 int  mi_mmvq_max_tokens(int type, int k);
 size_t mi_act_image_bytes(int type, int T, int k);

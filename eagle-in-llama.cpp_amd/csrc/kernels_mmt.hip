@@ -536,6 +536,142 @@ static bool mmt_inline_quant(int T, const mmvq_launch & L) {
     return L.act.norm ? per_wave <= 2 : per_wave <= maxsb;
 }
 
+
+// ---------------------------------------------------------------- big batches: one pass over the weights
+// Reference: ggml_cuda_op_mul_mat_cublas (R/ggml/src/ggml-cuda/ggml-cuda.cu:1164-1225: dequantise the whole matrix to fp16, then a BLAS GEMM)
+// and mul_mat_q (mmq.cuh:2590) for 9..63 tokens.  Here the arithmetic stays the CPU backend's (int8 activations, integer dots), so the
+// matrix-core mat-vec is re-tiled as a GEMM instead: a block owns 64 weight rows x 32 tokens, its 16 waves are 4 row groups x 4 token
+// groups (a wave = 16 rows x 8 tokens, the accumulator of the mat-vec kernel), and k is walked unit by unit with the activation tile of
+// the step (32 tokens x 256 int8 + scales + block sums, ~10 KB) double-buffered in LDS from the quantised image in HBM scratch.  Per step a
+// block moves 9 KB of weights (HBM; the four token quarters of a row block run on one XCD and share them in L2) against 10 KB of
+// activations (L2): balanced, every CU busy, weights streamed once for the whole batch instead of once per 24 tokens.
+#define BB_LDQ 272                      // bytes per token row of an activation tile (256 + 16: conflict-free 16-byte operand reads)
+template <int TYPE>
+__global__ void __launch_bounds__(1024) k_mmt_bb(const mmvq_launch L, const int T, const int n_rq) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
+    constexpr int TILE = mq_tfrag<TYPE>::TILE;
+    constexpr int DN = Q80 ? 8 : 1;                                  // activation scales per (token, unit)
+    constexpr int BUF = 32*BB_LDQ + 32*DN*4 + (Q80 ? 0 : 32*32);     // one tile: quants | scales | split block sums
+    const int k = L.k, nun = k/256, nsb_img = Q80 ? k/32 : nun;
+    const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
+    // block -> (row quad, token quarter): the quarters of one row quad get block ids 8 apart (one XCD under round-robin placement: speed only)
+    const int b = blockIdx.x, nq = (T + 31) / 32;
+    const int rq = (b & 7) + 8 * ((b >> 3) / nq), tq = (b >> 3) % nq;
+    if (rq >= n_rq) return;
+    const int rg = wave >> 2, tg = wave & 3;
+    const mmvq_mat & M = L.m[0];
+    const int row0 = rq*64 + rg*16, t0 = tq*32;
+    const bool rows_ok = row0 < M.rows;                              // the last row quad may hold fewer than four groups
+    const char * tp = M.W + (size_t)(rows_ok ? row0 : 0) * M.row_bytes;
+    // image (mi_quant_act): [T][k] int8 | [T][nsb] f32 d | ([T][k/16] i16 bsums) | rec32 [T][nsb][32] | rec16 [T][nsb][32]
+    const char * img = L.act.pre;
+    const float * img_d = (const float *)(img + (size_t) T*k);
+    const char * img_rec = Q80 ? nullptr : img + act_img_bytes(true, T, k) + (TYPE == GGML_TYPE_Q6_K ? (size_t) T*nsb_img*32 : 0);
+    // this thread's share of a tile: 16 bytes of quants (threads 0..511), one scale (next 32*DN threads), 16 bytes of block sums (next 64)
+    const int my_tok = t0 + (tid < 512 ? tid >> 4 : tid < 512 + 32*DN ? (tid - 512) / DN : (tid - 512 - 32*DN) >> 1);
+    const bool tok_ok = my_tok < T;
+    // a step = two units (one barrier per 512 k): the step's two activation tiles sit side by side in one LDS buffer
+    i32x4 rq4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; float rd[2] = {0.f, 0.f};
+    auto load_tile = [&](int step) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int u = 2*step + j;
+            if (u >= nun) break;
+            if (tid < 512) rq4[j] = tok_ok ? *(const i32x4 *)(img + (size_t) my_tok*k + u*256 + 16*(tid & 15)) : (i32x4)(0);
+            else if (tid < 512 + 32*DN) rd[j] = tok_ok ? img_d[(size_t) my_tok*nsb_img + u*DN + (tid - 512) % DN] : 0.f;
+            else if (!Q80 && tid < 512 + 32*DN + 64) rq4[j] = tok_ok ? ld16(img_rec + ((size_t) my_tok*nsb_img + u)*32 + 16*((tid - 512 - 32*DN) & 1)) : (i32x4)(0);
+        }
+    };
+    auto store_tile = [&](char * buf0, int step) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (2*step + j >= nun) break;
+            char * buf = buf0 + j*BUF;
+            if (tid < 512) *(i32x4 *)(buf + (tid >> 4)*BB_LDQ + 16*(tid & 15)) = rq4[j];
+            else if (tid < 512 + 32*DN) ((float *)(buf + 32*BB_LDQ))[tid - 512] = rd[j];
+            else if (!Q80 && tid < 512 + 32*DN + 64) *(i32x4 *)(buf + 32*BB_LDQ + 32*DN*4 + (tid - 512 - 32*DN)*16) = rq4[j];
+        }
+    };
+    mq_tfrag<TYPE> fa, fb;
+    load_tile(0);
+    fa.load(tp, lane, 0);
+    if (nun > 1) fb.load(tp + TILE, lane, 0);
+    store_tile(smem, 0);
+    __syncthreads();
+    float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
+    const int tok_w = t0 + 8*tg;                                    // first token of this wave
+    const bool mine = rows_ok && tok_w < T;
+    const int nsteps = (nun + 1) / 2;
+    for (int st = 0; st < nsteps; ++st) {
+        char * cur = smem + (st & 1)*2*BUF;
+        if (st + 1 < nsteps) load_tile(st + 1);
+        {
+            const int u = 2*st;
+            const mq_act A = { (const int8_t *) cur + 8*tg*BB_LDQ, BB_LDQ, (const float *)(cur + 32*BB_LDQ) + 8*tg*DN, cur + 32*BB_LDQ + 32*DN*4 + 8*tg*32, DN, T - tok_w };
+            if (mine) mq_proc<TYPE, 1>::run(fa, A, 0, lane, acc);
+            if (u + 2 < nun) fa.load(tp + (size_t)(u + 2)*TILE, lane, 0);
+        }
+        if (2*st + 1 < nun) {
+            const int u = 2*st + 1; const char * c1 = cur + BUF;
+            const mq_act A = { (const int8_t *) c1 + 8*tg*BB_LDQ, BB_LDQ, (const float *)(c1 + 32*BB_LDQ) + 8*tg*DN, c1 + 32*BB_LDQ + 32*DN*4 + 8*tg*32, DN, T - tok_w };
+            if (mine) mq_proc<TYPE, 1>::run(fb, A, 0, lane, acc);
+            if (u + 2 < nun) fb.load(tp + (size_t)(u + 2)*TILE, lane, 0);
+        }
+        if (st + 1 < nsteps) store_tile(smem + ((st + 1) & 1)*2*BUF, st + 1);
+        __syncthreads();
+    }
+    // classes (lanes l, l ^ 32) meet in registers; lanes kq < 2 hold row n, tokens tok_w + 4 kq + r
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[0][r] + __shfl_xor(acc[0][r], 32);
+    const int n = lane & 15, kq = lane >> 4, row = row0 + n;
+    if (mine && kq < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tok = tok_w + 4*kq + r;
+            if (tok < T) { float o = v[r]; if (M.res) o += M.res[(size_t) tok*M.r_tok + row]; if (M.relu) o = o > 0.f ? o : 0.f; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = o; }
+        }
+    }
+}
+template <int TYPE> static void mmt_bb_launch(hipStream_t st, int T, const mmvq_launch & L) {
+    constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
+    constexpr int DN = Q80 ? 8 : 1;
+    const size_t lds = 4 * (size_t)(32*BB_LDQ + 32*DN*4 + (Q80 ? 0 : 32*32));      // two buffers of two unit tiles
+    MI_ASSERT(L.act.pre && L.n_mat == 1 && L.m[0].rows % 16 == 0);
+    const int n_rq = (L.m[0].rows + 63) / 64, nq = (T + 31) / 32;
+    const int grid = ((n_rq + 7) / 8) * 8 * nq;
+    const int pi = mi_prof_begin(st, L, T, false);
+    k_mmt_bb<TYPE><<<grid, 1024, lds, st>>>(L, T, n_rq);
+    mi_prof_end(st, pi);
+}
+static void mmt_bb_dispatch(hipStream_t st, int type, int T, const mmvq_launch & L) {
+    switch (type) {
+        case GGML_TYPE_Q4_K: mmt_bb_launch<GGML_TYPE_Q4_K>(st, T, L); break;
+        case GGML_TYPE_Q5_K: mmt_bb_launch<GGML_TYPE_Q5_K>(st, T, L); break;
+        case GGML_TYPE_Q6_K: mmt_bb_launch<GGML_TYPE_Q6_K>(st, T, L); break;
+        case GGML_TYPE_Q8_0: mmt_bb_launch<GGML_TYPE_Q8_0>(st, T, L); break;
+        case GGML_TYPE_Q4_0: mmt_bb_launch<GGML_TYPE_Q4_0>(st, T, L); break;
+        default: MI_ABORT("mmt_bb: unsupported weight type %d", type);
+    }
+}
+static int mmt_bb_min_tokens() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_BB_MIN_T"); return e ? atoi(e) : 25; }(); return v; }
+// image of a whole big batch (all of k): a ring of 4 x 8 MiB slots next to the small-image ring, keyed like it
+#define MI_BIG_SLOTS 4
+#define MI_BIG_SLOT_BYTES ((size_t) 8 << 20)
+static const char * mmt_big_image(hipStream_t st, int type, int T, int t0, const mmvq_launch & L, mi_act_cache * cache, const void * key) {
+    if (!cache->big_pool) HIP_CHECK(hipMalloc((void **) &cache->big_pool, MI_BIG_SLOTS * MI_BIG_SLOT_BYTES));
+    const int kq = mi_traits(type).blck == 256;
+    int hit = -1;
+    if (key) for (int i = 0; i < MI_BIG_SLOTS; ++i) { const auto & e = cache->big[i]; if (e.key == key && e.epoch == cache->epoch && e.t0 == t0 && e.T == T && e.kq == kq && e.k == L.k) { hit = i; break; } }
+    if (hit < 0) {
+        hit = cache->big_next; cache->big_next = (cache->big_next + 1) % MI_BIG_SLOTS;
+        mi_quant_act(st, type, T, L.act, L.k, cache->big_pool + (size_t) hit * MI_BIG_SLOT_BYTES);
+        cache->big[hit] = { key, cache->epoch, t0, T, kq, L.k };
+    }
+    return cache->big_pool + (size_t) hit * MI_BIG_SLOT_BYTES;
+}
+
 // quantised image of tokens [t0, t0+T) x k-range of L in an HBM scratch slot (shared between launches reading the same activations)
 static const char * mmt_image(hipStream_t st, int type, int T, int t0, const mmvq_launch & L, mi_act_cache * cache, const void * key) {
     const int kq = mi_traits(type).blck == 256;
@@ -559,6 +695,21 @@ void mi_mmt_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_a
     // units, every later chunk adding to the output through the residual input.  Plain outputs only (the row norm needs the whole row).
     const int Tw = Ttot >= 24 ? 24 : (Ttot >= 16 ? 16 : (Ttot > 8 ? 8 : Ttot));
     const bool plain = L0.n_mat == 1 && !swiglu && L0.m[0].epi == EPI_F32 && !L0.m[0].relu && !L0.act.norm && !L0.act.X2;
+    if (plain && Ttot >= mmt_bb_min_tokens()) {
+        // one pass over the weights for the whole batch (a3); token passes only when the batch's int8 image outgrows a scratch slot
+        int tpass = Ttot;
+        while (tpass > 32 && mi_act_image_bytes(type, tpass, L0.k) > MI_BIG_SLOT_BYTES) tpass = (tpass / 2 + 31) / 32 * 32;
+        for (int t0 = 0; t0 < Ttot; t0 += tpass) {
+            const int T = (Ttot - t0) < tpass ? (Ttot - t0) : tpass;
+            mmvq_launch L = L0;
+            L.act.X += (size_t) t0 * L.act.xs;
+            L.m[0].out += (size_t) t0 * L.m[0].o_tok;
+            if (L.m[0].res) L.m[0].res += (size_t) t0 * L.m[0].r_tok;
+            L.act.pre = mmt_big_image(st, type, T, t0, L, cache, key);
+            mmt_bb_dispatch(st, type, T, L);
+        }
+        return;
+    }
     if (tmax < Tw && plain) {
         const int nun = L0.k / 256;
         int nch = 2, kc = 0;

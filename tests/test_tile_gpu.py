@@ -91,3 +91,33 @@ def test_tiled_kernel_token_counts_and_long_k(ea, gpu, tname):
                 g.set(rt, r)
             g.compute()
             assert rel(g.get(out).reshape(T, rows), want + (0 if r is None else r)) < 2e-5, (tname, rows, k, T, r is not None)
+
+
+@pytest.mark.parametrize("tname", ["q4_K", "q6_K", "q8_0", "q5_K", "q4_0"])
+def test_big_batch_one_pass_kernel_full_7b_rows(ea, gpu, tname):
+    """a3: prompts / wide tree verification (> 24 tokens) take k_mmt_ts -- waves split the tokens, k is cut into LDS-sized chunks that
+    accumulate through the residual input -- at the full row counts of the 7B matrices; checked on row slices by the restatement"""
+    t = QTYPES[tname]
+    rng = np.random.default_rng(77)
+    for rows, k, T in [(4096, 4096, 61), (4096, 4096, 128), (11008, 4096, 70), (4096, 11008, 61), (4096, 11008, 128), (512, 1024, 25), (256, 8192, 150)]:
+        if tname in ("q5_K", "q4_0") and rows * k > 4096 * 4096:
+            continue
+        w = qdata.random_blocks(t, rows, k, rng)
+        x = rng.standard_normal((T, k)).astype(np.float32)
+        res = rng.standard_normal((T, rows)).astype(np.float32)
+        rb = orc.row_bytes(t, k)
+        sel = np.r_[0:32, rows // 2:rows // 2 + 16, rows - 32:rows]
+        wsel = np.concatenate([w[r * rb:(r + 1) * rb] for r in sel])
+        want = orc.mul_mat_q(t, wsel, x, k, len(sel))
+        for r in (None, res):
+            g = ea.Graph(gpu, ea.USAGE_WEIGHTS)
+            a, b = g.tensor(t, k, rows), g.tensor(ea.F32, k, T)
+            c = g.mul_mat(a, b); out = c
+            if r is not None:
+                rt = g.tensor(ea.F32, rows, T); out = g.add(c, rt)
+            g.alloc(); g.set(a, w); g.set(b, x)
+            if r is not None:
+                g.set(rt, r)
+            g.compute()
+            got = g.get(out).reshape(T, rows)[:, sel]
+            assert rel(got, want + (0 if r is None else r[:, sel])) < 2e-5, (tname, rows, k, T, r is not None)
