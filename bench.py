@@ -10,16 +10,28 @@ Weights are synthetic (no checkpoints / network here): random valid quant blocks
 the exact Q4_K_M type mix of Vicuna-7B (4.0 GB of mat-mul weights streamed per target forward), constructed so
 that the target's greedy continuation is a fixed permutation of the vocabulary and the draft head predicts it
 with probability `accept_p` per token -- acceptance is decided by the real logits our kernels compute
-(eagle-in-llama.cpp_amd/host/model.cpp); `accept_rate` in the JSON line is measured, not assumed.
+(eagle-in-llama.cpp_amd/host/model.cpp); `accept_rate` in the JSON line is measured, not assumed, and it is a
+property of that synthetic dial, not of trained EAGLE weights (see `extra.accept_p_sweep` for tokens/s at other settings).
+
+Roofline of the dominant kernel family (quantised mat-vec): algorithmic bytes per launch over
+  * `achieved`: the rocprofv3 kernel-trace durations of the same K rounds, measured by running this very script as a child under
+    `rocprofv3 --kernel-trace` (`--rocprof-child`; the plugin brackets the rounds with a marker kernel and counts launches and bytes
+    without inserting anything between the kernels) -- the figure the committed profiles/ summary has to agree with;
+  * `hip_events`: HIP events around every launch on the plugin's stream in this process (raw pairs and net of an empty pair).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 N > 1 (one process per GPU, launched by torch.distributed.run): see DESIGN.md "multi-GPU".
 """
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N_DRAFT = 5
 PROMPT_LEN = 128
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
+MATVEC_KERNELS = ("k_mmt<", "k_mmt_bb<", "k_mmq<", "k_mmvq<")
 
 
 def load_pkg():
@@ -46,28 +59,32 @@ def prompt_tokens(seed, n=PROMPT_LEN, vocab=32000):
     return [1] + [int(x) for x in rng.integers(5, vocab, n - 1)]          # BOS + uniform{5..vocab-1}
 
 
-def plugin_profile(ea):
-    """HIP-event timing of every mat-vec launch inside the plugin (on the stream the kernels run on)."""
+def plugin_lib(ea):
     lib = C.CDLL(ea.require_plugin())
     lib.ggml_backend_mi355x_profile_begin.restype = None
     lib.ggml_backend_mi355x_profile_end.restype = C.c_int
     lib.ggml_backend_mi355x_profile_end.argtypes = [C.POINTER(C.c_double)]
+    lib.ggml_backend_mi355x_count_begin.restype = None
+    lib.ggml_backend_mi355x_count_end.restype = C.c_long
+    lib.ggml_backend_mi355x_count_end.argtypes = [C.POINTER(C.c_double)]
     return lib
 
 
 def pmc_traffic():
     """HBM bytes per mat-vec launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same command
-    (profiles/r01_pmc_traffic.json, written by scripts/pmc_summary.py; counters cannot be read from inside the run)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    (profiles/r02_pmc_traffic.json, scripts/pmc_summary.py; counters cannot be read from inside the run) -- labelled as such."""
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["hbm_bytes_per_launch"], name
+        except Exception:
+            continue
+    return None, None
 
 
-def cpu_baseline(ea, cfg, ftype):
-    """The reference's own ggml CPU backend (oracle/_ref, built from /root/reference) running the SAME driver on a
-    bounded sample of the same workload.  Falls back to nothing (null) when oracle/_ref is absent."""
+def cpu_baseline(ea, cfg, ftype, rounds=10):
+    """The reference's own ggml CPU backend (oracle/_ref, built from /root/reference) running the SAME driver on the same
+    128-token prompt for `rounds` speculative rounds.  Falls back to nothing (null) when oracle/_ref is absent."""
     import refapi                                                  # tests/refapi.py: the only place that knows oracle/_ref
     if not os.path.exists(refapi.REF_GGML_PATH):
         return None
@@ -78,17 +95,75 @@ def cpu_baseline(ea, cfg, ftype):
     threads = max(1, min(threads, 32))
     be = refapi.reference_cpu(ea, threads=threads)
     t0 = time.time()
-    tgt = ea.Model(be, cfg, ftype, n_ctx=256, seed=42)
-    dft = ea.Model(be, cfg, ftype, n_ctx=256, eagle_of=tgt, seed=42, accept_p=0.8)
-    prompt = prompt_tokens(1234, 16)
-    s = ea.SpecSession(tgt, dft, prompt)
-    rounds = 3
+    tgt = ea.Model(be, cfg, ftype, n_ctx=512, seed=42)
+    dft = ea.Model(be, cfg, ftype, n_ctx=512, eagle_of=tgt, seed=42, accept_p=0.8)
+    s = ea.SpecSession(tgt, dft, prompt_tokens(1234))
+    t_setup = time.time() - t0
     toks, st = s.rounds(rounds, n_draft=N_DRAFT)
     s.close(); dft.close(); tgt.close()
     return {"value": round(st["n_predict"] / st["t_decode_us"] * 1e6, 3), "unit": "tokens/s", "cores": threads, "kind": "reference",
-            "sample": f"{rounds} speculative rounds (n_draft={N_DRAFT}) after a 16-token prompt, same synthetic Vicuna-7B {ftype} + EAGLE head, "
-                      f"reference ggml CPU backend (AVX2 build), {threads} threads; setup {time.time()-t0:.0f}s not timed",
+            "sample": f"{rounds} speculative rounds (n_draft={N_DRAFT}) after the same {PROMPT_LEN}-token prompt, same synthetic Vicuna-7B {ftype} + EAGLE head, "
+                      f"reference ggml CPU backend (AVX2 build), {threads} threads; model build + prompt pass {t_setup:.0f}s not timed",
             "accept_rate": round(st["n_accept"] / max(1.0, st["n_drafted"]), 4)}
+
+
+def rocprof_child(args):
+    """Inner run for rocprofv3: build the models, prompt, warm-up, then K rounds bracketed by the plugin's marker kernel."""
+    ea = load_pkg()
+    lib = plugin_lib(ea)
+    be = ea.Backend.mi355x(0)
+    tgt = ea.Model(be, args.config, args.ftype, n_ctx=2048, seed=42)
+    dft = ea.Model(be, args.config, args.ftype, n_ctx=2048, eagle_of=tgt, seed=42, accept_p=args.accept_p)
+    sess = ea.SpecSession(tgt, dft, prompt_tokens(1234))
+    sess.rounds(max(args.warmup, 1), n_draft=N_DRAFT)
+    lib.ggml_backend_mi355x_count_begin()
+    sess.rounds(args.steps, n_draft=N_DRAFT)
+    nbytes = C.c_double(0)
+    n = lib.ggml_backend_mi355x_count_end(C.byref(nbytes))
+    sess.close()
+    print(json.dumps({"launches": int(n), "alg_bytes": nbytes.value}), flush=True)
+
+
+def rocprof_roofline(args):
+    """Runs this script under rocprofv3 --kernel-trace as a CHILD process and cuts the trace at the marker kernels."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="bench_rocprof_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--rocprof-child",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--config", args.config, "--ftype", args.ftype, "--accept-p", str(args.accept_p)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+        info = None
+        for line in r.stdout.splitlines():
+            if line.startswith("{") and "alg_bytes" in line:
+                info = json.loads(line)
+        files = glob.glob(out + "/**/*_kernel_trace.csv", recursive=True)
+        if info is None or not files:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        rows = list(csv.DictReader(open(files[0])))
+        rows.sort(key=lambda x: int(x["Start_Timestamp"]))
+        marks = [i for i, x in enumerate(rows) if "k_profile_mark" in x["Kernel_Name"]]
+        if len(marks) < 2:
+            return {"error": "marker kernels not found in the trace"}
+        sel = rows[marks[-2] + 1:marks[-1]]
+        mv = [x for x in sel if any(k in x["Kernel_Name"] for k in MATVEC_KERNELS)]
+        dur = sum(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in mv) * 1e-9
+        tot = sum(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in sel) * 1e-9
+        span = (int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])) * 1e-9 if sel else 0.0
+        keep = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(keep):                                   # leave the raw trace where profiles/ summaries are made from
+            try:
+                shutil.copy(files[0], os.path.join(keep, "bench_rocprof_kernel_trace.csv"))
+            except Exception:
+                pass
+        return {"launches": len(mv), "launches_counted_by_plugin": info["launches"], "alg_bytes": info["alg_bytes"], "matvec_s": dur,
+                "all_kernels_s": tot, "span_s": span, "n_dispatches": len(sel)}
+    except Exception as e:
+        return {"error": str(e)}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def main():
@@ -100,23 +175,35 @@ def main():
     ap.add_argument("--ftype", default="q4_k_m")
     ap.add_argument("--accept-p", type=float, default=0.8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child run (roofline.achieved then comes from HIP events)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the accept_p sweep and the tree / Q8_0 workloads")
+    ap.add_argument("--rocprof-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.rocprof_child:
+        return rocprof_child(args)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("EH_FORCE_TP"):      # EH_FORCE_TP=1: rehearse the TP path with a 1-rank communicator
         from bench_tp import main_tp           # one process per GPU, row-split tensor parallel over RCCL
         return main_tp(args, rank, world, local)
 
+    # the rocprofv3 pass first, while this process has not touched the GPU yet: it is a child process of its own
+    rp = None if args.no_rocprof else rocprof_roofline(args)
+
     import torch                                # plumbing only: barrier-free at N=1, used for cuda.synchronize()
     ea = load_pkg()
+    lib = plugin_lib(ea)
     be = ea.Backend.mi355x(0)                   # raises if the HIP plugin is missing: no CPU fallback on the product path
     tgt = ea.Model(be, args.config, args.ftype, n_ctx=2048, seed=42)
     dft = ea.Model(be, args.config, args.ftype, n_ctx=2048, eagle_of=tgt, seed=42, accept_p=args.accept_p)
     prompt = prompt_tokens(1234)
 
-    # non-speculative decode on the same model: the 1x the ">= 2x" target refers to
-    plain_toks, pst = ea.plain_generate(tgt, prompt, 64)
+    # non-speculative decode on the same model: the 1x the ">= 2x" target refers to.  Same treatment as the speculative path:
+    # device-side arg-max, and a warm pass before the timed one (first launches, weight re-layout, attribute set-up are not timed)
+    ea.plain_generate(tgt, prompt, 16)
+    plain_toks, pst = ea.plain_generate(tgt, prompt, 96)
     plain_tps = (pst["n_predict"] - 1) / pst["t_decode_us"] * 1e6
+    prompt_ms = pst["t_prompt_us"] / 1e3
 
     sess = ea.SpecSession(tgt, dft, prompt)
     if args.warmup > 0:
@@ -128,32 +215,93 @@ def main():
     dt = time.perf_counter() - t0
     value = st["n_predict"] / dt
 
-    # roofline of the dominant kernel (quantised mat-vec), same K rounds again with HIP events around every launch
-    prof = plugin_profile(ea)
-    prof.ggml_backend_mi355x_profile_begin()
+    # HIP events around every mat-vec launch, same K rounds again (on the stream the kernels are launched on)
+    lib.ggml_backend_mi355x_profile_begin()
     sess.rounds(args.steps, n_draft=N_DRAFT)
     out = (C.c_double * 4)()
-    n_launch = prof.ggml_backend_mi355x_profile_end(out)
+    n_launch = lib.ggml_backend_mi355x_profile_end(out)
     raw_ms, alg_bytes, pair_ms = out[0], out[1], out[2]
     sess.close()
-    # an event pair with nothing in between still measures `pair_ms` (queue markers): the kernel time is net of it
-    kern_ms = max(raw_ms - pair_ms * n_launch, 1e-9)
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if n_launch > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "quantised mat-vec family: k_mmq (int8 MFMA, 2..8 tokens) + k_mmvq (dp4a, 1 token)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(),
-                "launches": n_launch, "avg_launch_us": round(kern_ms * 1e3 / max(1, n_launch), 2),
-                "avg_launch_us_raw_event_pair": round(raw_ms * 1e3 / max(1, n_launch), 2), "empty_event_pair_us": round(pair_ms * 1e3, 2),
-                "algorithmic_bytes_per_launch": round(alg_bytes / max(1, n_launch))}
+    ev = {"launches": n_launch, "avg_launch_us_raw_event_pair": round(raw_ms * 1e3 / max(1, n_launch), 2), "empty_event_pair_us": round(pair_ms * 1e3, 2),
+          "avg_launch_us_net_of_empty_pair": round(max(raw_ms - pair_ms * n_launch, 1e-9) * 1e3 / max(1, n_launch), 2)}
+    bytes_per_launch = alg_bytes / max(1, n_launch)
+
+    if rp and "matvec_s" in rp and rp["launches"] > 0:
+        avg_us = rp["matvec_s"] / rp["launches"] * 1e6
+        bpl = rp["alg_bytes"] / max(1, rp["launches_counted_by_plugin"])
+        achieved = bpl / (avg_us * 1e-6) / 1e9
+        src = "rocprofv3 --kernel-trace of the same %d rounds in a child process of this run (durations between the plugin's marker kernels)" % args.steps
+        extra_rp = {"launches": rp["launches"], "launches_counted_by_plugin": rp["launches_counted_by_plugin"], "matvec_kernel_ms_per_round": round(rp["matvec_s"] * 1e3 / args.steps, 4),
+                    "all_kernel_ms_per_round": round(rp["all_kernels_s"] * 1e3 / args.steps, 4), "wall_ms_per_round_under_rocprof": round(rp["span_s"] * 1e3 / args.steps, 4)}
+    else:
+        avg_us = ev["avg_launch_us_net_of_empty_pair"]; bpl = bytes_per_launch
+        achieved = bpl / (avg_us * 1e-6) / 1e9 if n_launch else 0.0
+        src = "HIP events net of an empty event pair (rocprofv3 child run unavailable: %s)" % (rp or {}).get("error", "skipped")
+        extra_rp = None
+    traffic, traffic_src = pmc_traffic()
+    roofline = {"bound": "hbm", "kernel": "quantised mat-vec family: k_mmt (tiled weights, int8 MFMA, in-kernel Q8_K quantiser; 1..8 tokens)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": f"profiles/{traffic_src} (committed PMC pass, not this run)" if traffic_src else None,
+                "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": round(bpl), "source": src, "rocprof": extra_rp, "hip_events": ev}
 
     res = {"metric": "accepted tokens/sec + accept-rate, Vicuna-7B Q4_K_M + EAGLE, 1/8 GPU", "value": round(value, 2), "unit": "tokens/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 -> int32 (MFMA / dp4a) -> f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 -> int32 (MFMA) -> f32", "data": "synthetic",
            "config": {"workload": f"{args.config} {args.ftype} target + EAGLE head, chain/tree depth {N_DRAFT} (verify batch {N_DRAFT+1}), "
                                   f"{PROMPT_LEN}-token synthetic prompt, greedy", "n_draft": N_DRAFT, "accept_p_synthetic": args.accept_p},
            "accept_rate": round(st["n_accept"] / max(1.0, st["n_drafted"]), 4), "tokens_per_round": round(st["n_predict"] / args.steps, 3),
-           "plain_decode_tokens_per_s": round(plain_tps, 2), "speedup_vs_plain": round(value / plain_tps, 3),
+           "plain_decode_tokens_per_s": round(plain_tps, 2), "speedup_vs_plain": round(value / plain_tps, 3), "prompt_128_ms": round(prompt_ms, 2),
            "target_weight_bytes": tgt.weight_bytes, "draft_weight_bytes": dft.weight_bytes,
            "roofline": roofline}
+
+    if not args.no_extra:
+        extra = {}
+        # tokens/s as a function of the synthetic acceptance dial (measured, not modelled)
+        sweep = []
+        for ap_ in (0.0, 0.5, 0.8, 1.0):
+            d2 = ea.Model(be, args.config, args.ftype, n_ctx=2048, eagle_of=tgt, seed=42, accept_p=ap_)
+            s2 = ea.SpecSession(tgt, d2, prompt)
+            s2.rounds(2, n_draft=N_DRAFT)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            _, st2 = s2.rounds(20, n_draft=N_DRAFT)
+            torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+            s2.close(); d2.close()
+            sweep.append({"accept_p": ap_, "tokens_per_s": round(st2["n_predict"] / d1, 1), "tokens_per_round": round(st2["n_predict"] / 20, 3),
+                          "accept_rate": round(st2["n_accept"] / max(1.0, st2["n_drafted"]), 4), "ms_per_round": round(d1 / 20 * 1e3, 3)})
+        extra["accept_p_sweep"] = sweep
+        # the reference's TREE driver (host/tree_driver.cpp): 4 branches forking on p_split, greedy verification
+        try:
+            ts = ea.TreeSession(tgt, dft, prompt, n_seq_dft=4, n_draft=8, p_split=0.02, temp=0.0, temp_dft=4.0, top_k=8)
+            ts.run(8)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            tt, tst = ts.run(96)
+            torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+            ts.close()
+            extra["tree_driver"] = {"workload": "np 4, draft-max 8, p_split 0.02, draft temperature 4 (flat synthetic logits need it to fork), greedy verification", "tokens_per_s": round(len(tt) / d1, 1),
+                                    "tokens_per_round": round(tst["n_predict"] / max(1.0, tst["n_iters"]), 3), "forks": int(tst["n_forks"]), "max_verify_batch": int(tst["max_batch"])}
+        except Exception as e:
+            extra["tree_driver"] = {"error": str(e)}
+        res["extra"] = extra
+    dft.close(); tgt.close()
+
+    if not args.no_extra:
+        # BASELINE config 3: Q8_0 target, 10 branches, 60 drafts -> verification batches of > 60 tokens through the big-batch kernel (a3)
+        try:
+            t8 = ea.Model(be, args.config, "q8_0", n_ctx=2048, seed=42)
+            d8 = ea.Model(be, args.config, "q8_0", n_ctx=2048, eagle_of=t8, seed=42, accept_p=args.accept_p)
+            ts = ea.TreeSession(t8, d8, prompt, n_seq_dft=10, n_draft=60, p_split=0.01, temp=0.0, temp_dft=2.0, top_k=12)
+            ts.run(8)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            tt, tst = ts.run(64)
+            torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+            ts.close()
+            res["extra"]["config3_q8_0_tree"] = {"workload": "vicuna-7b q8_0 + EAGLE head, np 10, draft-max 60 (BASELINE configs[2])", "tokens_per_s": round(len(tt) / d1, 1),
+                                                 "tokens_per_round": round(tst["n_predict"] / max(1.0, tst["n_iters"]), 3), "max_verify_batch": int(tst["max_batch"]),
+                                                 "verify_ms_per_round": round(tst["t_verify_us"] / max(1.0, tst["n_iters"]) / 1e3, 3), "draft_ms_per_round": round(tst["t_draft_us"] / max(1.0, tst["n_iters"]) / 1e3, 3),
+                                                 "target_weight_bytes": t8.weight_bytes}
+            d8.close(); t8.close()
+        except Exception as e:
+            res["extra"]["config3_q8_0_tree"] = {"error": str(e)}
+
     if not args.no_cpu_baseline:
         try:
             res["cpu_baseline"] = cpu_baseline(ea, args.config, args.ftype)

@@ -109,8 +109,8 @@ def main_tp(args, rank, world, local):
     # roofline of rank 0's mat-vec launches (its shard of the weights): the same K rounds again, every rank takes part in the
     # collectives, rank 0 brackets its launches with HIP events (plugin profile hooks)
     n_acc, n_dr = st[2], st[1]
-    from bench import plugin_profile, pmc_traffic, HBM_PEAK_GBS
-    prof = plugin_profile(ea)
+    from bench import plugin_lib, HBM_PEAK_GBS
+    prof = plugin_lib(ea)
     if rank == 0: prof.ggml_backend_mi355x_profile_begin()
     for _ in range(args.steps):
         one_round()
@@ -121,7 +121,7 @@ def main_tp(args, rank, world, local):
         raw_ms, alg_bytes, pair_ms = out[0], out[1], out[2]
         kern_ms = max(raw_ms - pair_ms * n_launch, 1e-9)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if n_launch > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": "quantised mat-vec family on rank 0 (its weight shard): k_mmq + k_mmvq", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "quantised mat-vec family on rank 0 (its weight shard): k_mmt (HIP events net of an empty pair)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "launches": n_launch,
                     "avg_launch_us": round(kern_ms * 1e3 / max(1, n_launch), 2), "empty_event_pair_us": round(pair_ms * 1e3, 2),
                     "algorithmic_bytes_per_launch": round(alg_bytes / max(1, n_launch))}
@@ -129,7 +129,7 @@ def main_tp(args, rank, world, local):
     if rank == 0:
         res = {"metric": "accepted tokens/sec + accept-rate, Vicuna-7B Q4_K_M + EAGLE, 1/8 GPU", "value": round(n_tok / dt, 2), "unit": "tokens/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 -> int32 (MFMA / dp4a) -> f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "q4_K/q6_K x int8 -> int32 (MFMA) -> f32", "data": "synthetic",
                "config": {"workload": f"{args.config} {args.ftype} target row-split TP={world} (2 RCCL all-reduces/layer) + EAGLE head on rank 0, depth {N_DRAFT}, "
                                       f"{PROMPT_LEN}-token synthetic prompt, greedy", "n_draft": N_DRAFT, "accept_p_synthetic": args.accept_p},
                "accept_rate": round(n_acc / max(1.0, n_dr), 4), "tokens_per_round": round(n_tok / args.steps, 3),

@@ -449,9 +449,25 @@ static void ensure_lds_attr(const void * fn, size_t bytes) {
 }
 // ---- optional HIP-event profile of every mat-vec launch (bench.py roofline; off by default, zero cost when off)
 struct prof_rec { hipEvent_t a, b; double bytes; };
-static bool g_prof_on = false;
-static std::vector<prof_rec> g_prof, g_prof_cal;     // g_prof_cal: empty event pairs, the cost of the bracket itself
 static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+// count-only mode (no events between the kernels: the launch sequence is the product's): launches and algorithmic bytes between
+// count_begin / count_end, and a named marker kernel so that a rocprofv3 kernel trace of the same process can be cut at the same places
+static bool g_count_on = false; static double g_count_bytes = 0; static long g_count_n = 0;
+__global__ void k_profile_mark(int * p) { if (p && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *p = 0; }
+extern "C" __attribute__((visibility("default"))) void ggml_backend_mi355x_count_begin(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_count_on = true; g_count_bytes = 0; g_count_n = 0;
+    k_profile_mark<<<1, 64, 0, hipStreamPerThread>>>(nullptr); (void) hipStreamSynchronize(hipStreamPerThread);
+}
+extern "C" __attribute__((visibility("default"))) long ggml_backend_mi355x_count_end(double * bytes) {
+    (void) hipDeviceSynchronize();
+    k_profile_mark<<<1, 64, 0, hipStreamPerThread>>>(nullptr); (void) hipStreamSynchronize(hipStreamPerThread);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_count_on = false; if (bytes) *bytes = g_count_bytes;
+    return g_count_n;
+}
+static std::vector<prof_rec> g_prof, g_prof_cal;     // g_prof_cal: empty event pairs, the cost of the bracket itself
 extern "C" __attribute__((visibility("default"))) void ggml_backend_mi355x_profile_begin(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto & r : g_prof) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
@@ -489,6 +505,7 @@ static inline size_t lds_total(bool ktype, int T, int k, int NW) { return act_ld
 
 // profile hooks shared with kernels_mmq.hip: returns a record index (or -1 when profiling is off)
 int mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual) {
+    if (g_count_on) { std::lock_guard<std::mutex> lk(g_prof_mu); g_count_bytes += mi_launch_bytes(L, T, dual); g_count_n++; }
     if (!g_prof_on) return -1;
     {   // every 64th launch: one empty pair right before, same stream, same queue state
         std::lock_guard<std::mutex> lk(g_prof_mu);

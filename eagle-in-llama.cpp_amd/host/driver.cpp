@@ -234,30 +234,35 @@ EH_API int eh_spec_draft(void * sp, int n_draft, float p_min, int32_t * drafts, 
 EH_API int eh_spec_verify(void * sp, int32_t * out_tokens, double * stats) { SpecSession * ss = (SpecSession *) sp; return spec_verify(ss->s, out_tokens, stats); }
 EH_API void eh_spec_state(void * sp, int32_t * n_past, int32_t * id_last) { SpecSession * ss = (SpecSession *) sp; *n_past = ss->s.n_past; *id_last = ss->s.id_last; }
 
-// Plain autoregressive decoding (what the speculative path must beat by >= 2x)
+// Plain autoregressive decoding (what the speculative path must beat by >= 2x).  Like the speculative path it takes the greedy token with
+// GGML_OP_ARGMAX on the device (4 bytes come back instead of a 128 KB logits row); EH_HOST_ARGMAX=1 fetches the logits and scans them on
+// the host as the reference's sampler does.
 EH_API int eh_plain_run(void * tgt, const int32_t * prompt, int n_prompt, int n_predict, int32_t * out_tokens, double * stats) {
     Model * T = (Model *) tgt;
+    static const bool host_argmax = getenv("EH_HOST_ARGMAX") != nullptr;
     for (int i = 0; i < ST_COUNT; ++i) stats[i] = 0;
     const double t0 = now_us();
     T->kv.clear();
     Batch b;
     for (int i = 0; i < n_prompt; ++i) b.add(prompt[i], i, 0, i == n_prompt - 1);
+    T->want_logits = host_argmax;
     int rc = T->decode(b, false);
-    if (rc) return -1000 - rc;
+    if (rc) { T->want_logits = true; return -1000 - rc; }
     const double t1 = now_us();
     stats[ST_T_PROMPT_US] = t1 - t0;
     int n = 0, n_past = n_prompt;
-    int id = argmax(T->logits_ith(n_prompt - 1), T->cfg.n_vocab);
+    int id = T->argmax_ith(n_prompt - 1);
     out_tokens[n++] = id;
     while (n < n_predict && n_past + 1 < T->cfg.n_ctx) {
         b.clear(); b.add(id, n_past, 0, true);
         rc = T->decode(b, false);
         stats[ST_N_TARGET_CALLS] += 1;
-        if (rc) return -20 - rc;
+        if (rc) { T->want_logits = true; return -20 - rc; }
         n_past++;
-        id = argmax(T->logits_ith(0), T->cfg.n_vocab);
+        id = T->argmax_ith(0);
         out_tokens[n++] = id;
     }
+    T->want_logits = true;
     stats[ST_N_PREDICT] = n; stats[ST_T_DECODE_US] = now_us() - t1;
     return n;
 }

@@ -54,6 +54,13 @@ GGML_MI355X_API ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type
  * bytes (weights + fp32 activations + outputs); returns the number of launches.  Used by bench.py. */
 GGML_MI355X_API void ggml_backend_mi355x_profile_begin(void);
 GGML_MI355X_API int  ggml_backend_mi355x_profile_end(double * out);
+/* count-only variant for runs under rocprofv3: no events are inserted (the launch sequence is the product's); between begin and end the
+ * plugin counts quantised mat-vec launches and their algorithmic bytes, and both calls launch the marker kernel `k_profile_mark`, so the
+ * kernel trace of the same process can be cut at exactly these points (bench.py --rocprof-child). */
+GGML_MI355X_API void ggml_backend_mi355x_count_begin(void);
+GGML_MI355X_API long ggml_backend_mi355x_count_end(double * bytes);
+/* row-split arithmetic of the split buffer type (get_row_split, R/ggml/src/ggml-cuda/ggml-cuda.cu:735-748), for host-side tests */
+GGML_MI355X_API void ggml_backend_mi355x_row_split(int64_t nrows, const float * tensor_split, int n_dev, int id, int64_t * lo, int64_t * hi);
 
 #ifdef __cplusplus
 }

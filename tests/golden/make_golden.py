@@ -82,7 +82,34 @@ def main():
     out.update(at_q=q, at_k=kc.view(np.uint16), at_v=vc.view(np.uint16), at_mask=mask, at_scale=np.float32(scale), at_hkv=Hkv,
                at_y=g.get(res).reshape(T, H, d).copy())
     np.savez_compressed(os.path.join(HERE, "small_ops.npz"), **out)
+    model_forward_fixture(ea, scalar)
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
+
+
+def model_forward_fixture(ea, scalar):
+    """one llama forward and one EAGLE-head forward on the tiny synthetic GGUF-shaped pair (n_embd 256, 4 heads, n_ff 768,
+    n_vocab 512, 2 layers, Q4_K_M mix; weights regenerated from the seed by host/model.cpp), computed by the REAL reference CPU backend
+    (scalar build, ISA independent) through the build_llama / build_eagle mirrors: prompt, single token, a 3-branch tree batch with shared
+    positions, and the draft head fed with the target's features.  tests/test_golden_model.py replays them."""
+    cfg, ftype, seed = "tiny", "q4_k_m", 3
+    m = ea.Model(scalar, cfg, ftype, n_ctx=256, seed=seed, predictable=False)
+    d = ea.Model(scalar, cfg, ftype, n_ctx=256, eagle_of=m, seed=seed, predictable=False)
+    out = dict(config=cfg, ftype=ftype, seed=np.int32(seed))
+    p_tok, p_pos = list(range(5, 21)), list(range(16))
+    lg, hid = m.decode(p_tok, p_pos); out.update(p_tok=np.int32(p_tok), p_pos=np.int32(p_pos), p_logits=lg, p_hidden=hid)
+    lg1, hid1 = m.decode([77], [16]); out.update(s_tok=np.int32([77]), s_pos=np.int32([16]), s_logits=lg1, s_hidden=hid1)
+    h = ea._model_sigs()
+    m.kv_seq_rm(0, 17, -1)
+    for sq in (1, 2, 3):
+        h.eh_model_kv_seq_cp(m.h, 0, sq, -1, -1)
+    t_tok, t_pos, t_seq = [10, 11, 12, 13, 14, 15], [17, 18, 17, 18, 17, 18], [1, 1, 2, 2, 3, 3]
+    lgt, hidt = m.decode(t_tok, t_pos, seq=t_seq); out.update(t_tok=np.int32(t_tok), t_pos=np.int32(t_pos), t_seq=np.int32(t_seq), t_logits=lgt, t_hidden=hidt)
+    e_tok, e_pos = [30, 31, 32], [1, 2, 3]
+    lgd, hidd = d.decode(e_tok, e_pos, hidd=hid[:3]); out.update(e_tok=np.int32(e_tok), e_pos=np.int32(e_pos), e_logits=lgd, e_hidden=hidd)
+    lgd2, hidd2 = d.decode([33], [4], hidd=hidd[2:3]); out.update(e2_tok=np.int32([33]), e2_pos=np.int32([4]), e2_logits=lgd2, e2_hidden=hidd2)
+    d.close(); m.close()
+    out = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 else v) for k, v in out.items()}
+    np.savez_compressed(os.path.join(HERE, "model_forward_tiny.npz"), **out)
 
 
 if __name__ == "__main__":
