@@ -482,6 +482,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
         if (c.done[i] || is_view_op(t->op) || mi_nelements(t) == 0) continue;
         ggml_tensor * nx = (i + 1 < n) ? g->nodes[i + 1] : nullptr;
         const bool single_use = fuse && c.n_uses(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
+        { static const bool trace = getenv("GGML_MI355X_TRACE_OPS") != nullptr; if (trace) MI_LOG("node %4d op %2d %-24s [%lld %lld %lld] src0 %s src1 %s", i, (int) t->op, t->name, (long long) t->ne[0], (long long) t->ne[1], (long long) t->ne[2], t->src[0] ? t->src[0]->name : "-", t->src[1] ? t->src[1]->name : "-"); }
 
         switch (t->op) {
             case GGML_OP_RMS_NORM: {

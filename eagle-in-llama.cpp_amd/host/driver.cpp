@@ -65,7 +65,7 @@ static int spec_prompt(SpecState & s, const int32_t * prompt, int n) {
 }
 
 // draft phase of a round (runs where the EAGLE head lives: rank 0 under tensor parallelism)
-static int spec_draft(SpecState & s, int n_draft, float p_min, double * st) {
+static int spec_draft(SpecState & s, int n_draft, float p_min, double * st, bool defer = false) {
     Model & T = *s.tgt, & D = *s.dft;
     const int E = T.cfg.n_embd, V = T.cfg.n_vocab;
     const double t0 = now_us();
@@ -80,9 +80,20 @@ static int spec_draft(SpecState & s, int n_draft, float p_min, double * st) {
     // (Model::decode_chain); EH_STEPWISE_DRAFT=1 keeps the reference's one-decode-per-step loop
     if (s.fused_chain && p_min <= 0.0f && n_draft > 1 && D.cfg.tp_size == 1) {
         std::vector<int32_t> ids;
-        const int rc = D.decode_chain(d, n_draft, ids);
+        const int rc = D.decode_chain(d, n_draft, ids, defer);
         if (rc == 0) {
             st[ST_N_DRAFT_CALLS] += 1; st[ST_N_DRAFTED] += n_draft;
+            if (defer) {
+                // the chain is running: prepare the verification batch (shape known: id_last + n_draft tokens at consecutive positions) meanwhile
+                Batch & b = s.bt; b.clear();
+                for (int i = 0; i <= n_draft; ++i) b.add(0, s.n_past + i, 0, true);
+                s.tgt->want_logits = !s.device_argmax;
+                const int rp = s.tgt->decode_prepare(b);
+                s.tgt->want_logits = true;
+                (void) rp;                                     // a failed preparation is simply redone (and reported) by decode()
+                const int rw = D.chain_wait(ids);
+                if (rw) return -10 + rw;
+            }
             s.drafts = ids;
             st[ST_T_DRAFT_US] += now_us() - t0;
             return (int) s.drafts.size();
@@ -146,7 +157,8 @@ static int spec_verify(SpecState & s, int32_t * out, double * st) {
     return n_out;
 }
 static int spec_round(SpecState & s, int n_draft, float p_min, int32_t * out, double * st) {
-    const int nd = spec_draft(s, n_draft, p_min, st);
+    static const bool overlap = getenv("EH_NO_OVERLAP") == nullptr;      // prepare the verification graph while the draft chain runs
+    const int nd = spec_draft(s, n_draft, p_min, st, overlap);
     if (nd < 0) return nd;
     return spec_verify(s, out, st);
 }

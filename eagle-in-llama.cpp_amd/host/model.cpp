@@ -400,92 +400,133 @@ void Model::build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<C
 }
 
 // ------------------------------------------------------------------ decode
-int Model::decode(const Batch & b, bool want_hidden) {
+// llama_decode in two halves so that a driver can overlap host work with the GPU: decode_prepare() does everything that depends only
+// on the batch's SHAPE (positions, seq ids, output flags): KV slots, graph build, allocation, the pos / mask / out_ids part of the input
+// image; decode() then only gathers the embeddings (+ hidden rows), uploads, launches and waits.  The speculative driver prepares the
+// verification batch while the draft chain is still running on the device (its token ids are the only thing it has to wait for).
+static bool same_shape(const Batch & a, const Batch & b) {
+    return a.pos == b.pos && a.seq_first == b.seq_first && a.seq_mask == b.seq_mask && a.logits == b.logits;
+}
+void Model::decode_abandon() { if (pend.valid) { kv = pend.kv_saved; pend.valid = false; } }
+int Model::decode_prepare(const Batch & b) {
+    decode_abandon();
     const double t0 = now_us();
+    Pending & P = pend;
     const int T = b.n_tokens();
     if (T <= 0) return -1;
-    if (cfg.eagle && (int) b.hidd.size() != T * cfg.n_embd) return -2;
-    for (int i = 0; i < T; ++i) if (b.token[i] < 0 || b.token[i] >= cfg.n_vocab) return -6;       // llama_decode: "invalid token" (R/src/llama.cpp:9500)
     // cells claimed by find_slot are given back when the decode fails (llama_kv_slot_restorer, R/src/llama.cpp:9518-9546)
-    const KVCache kv_saved = kv;
+    P.kv_saved = kv;
     if (!kv.find_slot(b)) return 1;
     const uint32_t pad = 32;                                 // llama_kv_cache_get_padding without flash-attn
     kv.n = std::min(kv.size, std::max(pad, (kv.cell_max() + pad - 1) / pad * pad));
     const int n_kv = (int) kv.n, kv_head = (int) kv.head;
     static const bool force_tp = getenv("EH_FORCE_TP") != nullptr;     // run the segmented path + collectives even with one rank (single-GPU rehearsal)
-    const bool tp = cfg.tp_size > 1 || (force_tp && allreduce && !cfg.eagle);
-    if (tp && !allreduce) { kv = kv_saved; return -5; }
+    P.tp = cfg.tp_size > 1 || (force_tp && allreduce && !cfg.eagle);
+    if (P.tp && !allreduce) { kv = P.kv_saved; return -5; }
     const int E = cfg.n_embd;
-    std::vector<Cut> cuts;                                   // tensor parallel: partial sums to all-reduce, and where the graph is cut
+    P.cuts.clear();
     n_outputs = 0; out_ids.clear();
     for (int i = 0; i < T; ++i) if (b.logits[i]) { out_ids.push_back(i); n_outputs++; }
     if (n_outputs == 0) { out_ids.push_back(T - 1); n_outputs = 1; }
 
     mh::Ctx & g = *gctx;
     g.reset_graph();
-    ggml_tensor * inp_embd = g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd");
-    ggml_tensor * inp_hidd = cfg.eagle ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_hidd") : nullptr;
-    ggml_tensor * inp_pos  = g.new_tensor(GGML_TYPE_I32, T, 1, 1, 1, "inp_pos");
+    P.inp_embd = g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd");
+    P.inp_hidd = cfg.eagle ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_hidd") : nullptr;
+    P.inp_pos  = g.new_tensor(GGML_TYPE_I32, T, 1, 1, 1, "inp_pos");
     const int Tpad = (T + GGML_KQ_MASK_PAD - 1) / GGML_KQ_MASK_PAD * GGML_KQ_MASK_PAD;
-    ggml_tensor * kq_mask  = g.new_tensor(GGML_TYPE_F32, n_kv, Tpad, 1, 1, "KQ_mask");
-    ggml_tensor * inp_out  = g.new_tensor(GGML_TYPE_I32, n_outputs, 1, 1, 1, "inp_out_ids");
-    for (ggml_tensor * t : {inp_embd, inp_hidd, inp_pos, kq_mask, inp_out}) if (t) t->flags |= GGML_TENSOR_FLAG_INPUT;
+    P.kq_mask  = g.new_tensor(GGML_TYPE_F32, n_kv, Tpad, 1, 1, "KQ_mask");
+    P.inp_out  = g.new_tensor(GGML_TYPE_I32, n_outputs, 1, 1, 1, "inp_out_ids");
+    for (ggml_tensor * t : {P.inp_embd, P.inp_hidd, P.inp_pos, P.kq_mask, P.inp_out}) if (t) t->flags |= GGML_TENSOR_FLAG_INPUT;
 
-    StepIO io{ inp_embd, inp_hidd, inp_pos, kq_mask, inp_out, T, n_outputs, n_kv, kv_head };
-    ggml_tensor * result_norm = nullptr, * result_output = nullptr, * result_argmax = nullptr;
-    build_forward(g, io, tp, &cuts, result_norm, result_output, result_argmax);
-    const bool head_here = !tp || cfg.tp_rank == 0;          // TP: the LM head (and the hidden-state channel) live on rank 0
+    StepIO io{ P.inp_embd, P.inp_hidd, P.inp_pos, P.kq_mask, P.inp_out, T, n_outputs, n_kv, kv_head };
+    P.result_norm = nullptr; P.result_output = nullptr; P.result_argmax = nullptr;
+    build_forward(g, io, P.tp, &P.cuts, P.result_norm, P.result_output, P.result_argmax);
+    P.head_here = !P.tp || cfg.tp_rank == 0;                 // TP: the LM head (and the hidden-state channel) live on rank 0
     last_n_nodes = (int) g.nodes.size();
-    if (!g.alloc()) { kv = kv_saved; return -3; }
+    if (!g.alloc()) { kv = P.kv_saved; return -3; }
     const double t1 = now_us();
 
     // ---- inputs (llama_set_inputs, R/src/llama-context.cpp:61-210).  The input tensors were created first, so they sit
     // back to back in the compute buffer: their host image is assembled in page-locked memory and goes up as ONE
     // asynchronous copy ordered before the graph (the reference issues one blocking ggml_backend_tensor_set per input).
-    ggml_tensor * inputs[5] = { inp_embd, inp_hidd, inp_pos, kq_mask, inp_out };
-    size_t span = 0; bool packed = true;
+    ggml_tensor * inputs[5] = { P.inp_embd, P.inp_hidd, P.inp_pos, P.kq_mask, P.inp_out };
+    P.span = 0; P.packed = true;
     for (ggml_tensor * t : inputs) if (t) {
-        const ptrdiff_t off = (char *) t->data - (char *) inp_embd->data;
-        if (t->buffer != inp_embd->buffer || off < 0 || (size_t) off > ((size_t) 64 << 20)) { packed = false; break; }
-        span = std::max(span, (size_t) off + mh::nbytes(t));
+        const ptrdiff_t off = (char *) t->data - (char *) P.inp_embd->data;
+        if (t->buffer != P.inp_embd->buffer || off < 0 || (size_t) off > ((size_t) 64 << 20)) { P.packed = false; break; }
+        P.span = std::max(P.span, (size_t) off + mh::nbytes(t));
     }
-    if (packed && span > stage_cap) {
+    if (P.packed && P.span > stage_cap) {
         if (stage_in) { be->synchronize(); be->host_free(stage_in); }
-        stage_cap = span + span/2 + 4096; stage_in = (char *) be->host_alloc(stage_cap);
+        stage_cap = P.span + P.span/2 + 4096; stage_in = (char *) be->host_alloc(stage_cap);
     }
-    static thread_local std::vector<char> unpacked;
-    auto host_of = [&](ggml_tensor * t) -> char * {
-        if (packed) return stage_in + ((char *) t->data - (char *) inp_embd->data);
-        unpacked.resize(mh::nbytes(t)); return unpacked.data();
-    };
-    auto flush = [&](ggml_tensor * t, char * h) { if (!packed) g.set(t, h, 0, mh::nbytes(t)); };
-    {
-        float * embd = (float *) host_of(inp_embd);
-        for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; h2f_row(src, embd + (size_t) i * E, E); }
-        flush(inp_embd, (char *) embd);
-    }
-    if (inp_hidd) { char * h = host_of(inp_hidd); memcpy(h, b.hidd.data(), (size_t) T * E * 4); flush(inp_hidd, h); }
-    { char * h = host_of(inp_pos); memcpy(h, b.pos.data(), (size_t) T * 4); flush(inp_pos, h); }
-    { char * h = host_of(inp_out); memcpy(h, out_ids.data(), (size_t) n_outputs * 4); flush(inp_out, h); }
-    {
-        float * mask = (float *) host_of(kq_mask);
+    if (P.packed) {      // shape-dependent part of the image: positions, output rows, mask
+        auto host_of = [&](ggml_tensor * t) -> char * { return stage_in + ((char *) t->data - (char *) P.inp_embd->data); };
+        memcpy(host_of(P.inp_pos), b.pos.data(), (size_t) T * 4);
+        memcpy(host_of(P.inp_out), out_ids.data(), (size_t) n_outputs * 4);
+        float * mask = (float *) host_of(P.kq_mask);
         std::fill(mask, mask + (size_t) n_kv * T, -INFINITY);        // rows T..Tpad-1 are padding no kernel reads (R pads for flash-attn only)
         for (int j = 0; j < T; ++j) {
             const uint64_t sbit = 1ull << b.seq_first[j]; const int32_t pos = b.pos[j];
             float * row = mask + (size_t) j * n_kv;
             for (int i = 0; i < n_kv; ++i) if ((kv.cells[i].seqs & sbit) && kv.cells[i].pos <= pos) row[i] = 0.0f;
         }
-        flush(kq_mask, (char *) mask);
     }
-    if (packed) g.set_async(inp_embd, stage_in, 0, span);
+    P.shape = b; P.shape.token.clear(); P.shape.hidd.clear();
+    P.T = T; P.n_kv = n_kv; P.want_logits = want_logits;
+    P.valid = true;
+    t_build_us += t1 - t0; t_upload_us += now_us() - t1;
+    return 0;
+}
+
+int Model::decode(const Batch & b, bool want_hidden) {
+    const int T = b.n_tokens();
+    if (T <= 0) return -1;
+    if (cfg.eagle && (int) b.hidd.size() != T * cfg.n_embd) { decode_abandon(); return -2; }
+    for (int i = 0; i < T; ++i) if (b.token[i] < 0 || b.token[i] >= cfg.n_vocab) { decode_abandon(); return -6; }       // llama_decode: "invalid token" (R/src/llama.cpp:9500)
+    if (!(pend.valid && pend.want_logits == want_logits && same_shape(pend.shape, b))) {
+        const int rc = decode_prepare(b);
+        if (rc) return rc;
+    }
+    Pending & P = pend;
+    P.valid = false;
+    const double t1 = now_us();
+    const int E = cfg.n_embd, n_kv = P.n_kv;
+    mh::Ctx & g = *gctx;
+    static thread_local std::vector<char> unpacked;
+    auto host_of = [&](ggml_tensor * t) -> char * {
+        if (P.packed) return stage_in + ((char *) t->data - (char *) P.inp_embd->data);
+        unpacked.resize(mh::nbytes(t)); return unpacked.data();
+    };
+    auto flush = [&](ggml_tensor * t, char * h) { if (!P.packed) g.set(t, h, 0, mh::nbytes(t)); };
+    {
+        float * embd = (float *) host_of(P.inp_embd);
+        for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; h2f_row(src, embd + (size_t) i * E, E); }
+        flush(P.inp_embd, (char *) embd);
+    }
+    if (P.inp_hidd) { char * h = host_of(P.inp_hidd); memcpy(h, b.hidd.data(), (size_t) T * E * 4); flush(P.inp_hidd, h); }
+    if (!P.packed) {
+        { char * h = host_of(P.inp_pos); memcpy(h, b.pos.data(), (size_t) T * 4); flush(P.inp_pos, h); }
+        { char * h = host_of(P.inp_out); memcpy(h, out_ids.data(), (size_t) n_outputs * 4); flush(P.inp_out, h); }
+        float * mask = (float *) host_of(P.kq_mask);
+        std::fill(mask, mask + (size_t) n_kv * T, -INFINITY);
+        for (int j = 0; j < T; ++j) {
+            const uint64_t sbit = 1ull << b.seq_first[j]; const int32_t pos = b.pos[j];
+            float * row = mask + (size_t) j * n_kv;
+            for (int i = 0; i < n_kv; ++i) if ((kv.cells[i].seqs & sbit) && kv.cells[i].pos <= pos) row[i] = 0.0f;
+        }
+        flush(P.kq_mask, (char *) mask);
+    }
+    if (P.packed) g.set_async(P.inp_embd, stage_in, 0, P.span);
     const double t2 = now_us();
 
     // ---- compute, then the outputs by asynchronous copies into page-locked memory, one wait for everything
     enum ggml_status st = GGML_STATUS_SUCCESS;
-    if (!tp) st = g.compute_async();
+    if (!P.tp) st = g.compute_async();
     else {
         int n0 = 0;
-        for (auto & c : cuts) {
+        for (auto & c : P.cuts) {
             st = g.compute_range(n0, c.node_end); if (st != GGML_STATUS_SUCCESS) break;
             allreduce(allreduce_user, c.t->data, mh::nelements(c.t)); n_allreduce++;
             n0 = c.node_end;
@@ -493,26 +534,26 @@ int Model::decode(const Batch & b, bool want_hidden) {
         if (st == GGML_STATUS_SUCCESS) st = g.compute_range(n0, (int) g.nodes.size());
     }
     const double t3a = now_us();
-    if (st == GGML_STATUS_SUCCESS && head_here && result_argmax) {
+    if (st == GGML_STATUS_SUCCESS && P.head_here && P.result_argmax) {
         logits.clear();
         if (ids_stage.size() < (size_t) n_outputs) ids_stage.resize((size_t) n_outputs + 64);
-        g.get_async(result_argmax, ids_stage.data(), 0, (size_t) n_outputs * 4);
-        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(result_norm, hidden.data(), 0, hidden.size() * 4); }
-    } else if (st == GGML_STATUS_SUCCESS && head_here) {
+        g.get_async(P.result_argmax, ids_stage.data(), 0, (size_t) n_outputs * 4);
+        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(P.result_norm, hidden.data(), 0, hidden.size() * 4); }
+    } else if (st == GGML_STATUS_SUCCESS && P.head_here) {
         logits.resize((size_t) n_outputs * cfg.n_vocab);
-        g.get_async(result_output, logits.data(), 0, logits.size() * 4);
-        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(result_norm, hidden.data(), 0, hidden.size() * 4); }
+        g.get_async(P.result_output, logits.data(), 0, logits.size() * 4);
+        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(P.result_norm, hidden.data(), 0, hidden.size() * 4); }
     } else { logits.clear(); hidden.clear(); }
     be->synchronize();
     const double t3 = now_us();
     g.t_issue_us += t3a - t2; g.t_wait_us += t3 - t3a;
-    if (st != GGML_STATUS_SUCCESS) { kv = kv_saved; return st == GGML_STATUS_ABORTED ? 2 : -4; }
+    if (st != GGML_STATUS_SUCCESS) { kv = P.kv_saved; return st == GGML_STATUS_ABORTED ? 2 : -4; }
     argmax_ids.clear();
-    if (head_here && result_argmax) { const int32_t * p = (const int32_t *) ids_stage.data(); argmax_ids.assign(p, p + n_outputs); }
+    if (P.head_here && P.result_argmax) { const int32_t * p = (const int32_t *) ids_stage.data(); argmax_ids.assign(p, p + n_outputs); }
     kv.head += T;
     if (kv.head >= kv.size) kv.head = 0;
     const double t4 = now_us();
-    t_build_us += t1 - t0; t_upload_us += t2 - t1; t_compute_us += t3 - t2; t_download_us += t4 - t3; n_decode++;
+    t_upload_us += t2 - t1; t_compute_us += t3 - t2; t_download_us += t4 - t3; n_decode++;
     return 0;
 }
 
@@ -527,8 +568,9 @@ int Model::argmax_ith(int i) const {
     return -1;
 }
 // ------------------------------------------------------------------ fused greedy draft chain
-int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> & ids) {
+int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> & ids, bool defer_wait) {
     const double t0 = now_us();
+    decode_abandon();
     ids.clear();
     const int T0 = first.n_tokens(), E = cfg.n_embd;
     if (!cfg.eagle || cfg.tp_size > 1 || T0 <= 0 || n_steps < 1) return -1;
@@ -630,14 +672,24 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     const double t3a = now_us();
     if (ids_stage.size() < (size_t) n_steps) ids_stage.resize((size_t) n_steps + 64);
     if (st == GGML_STATUS_SUCCESS) for (int j = 0; j < n_steps; ++j) g.get_async(amax[j], (int32_t *) ids_stage.data() + j, 0, 4);
+    g.t_issue_us += t3a - t2;
+    t_build_us += t1 - t0; t_upload_us += t2 - t1;
+    if (st != GGML_STATUS_SUCCESS) { be->synchronize(); kv = kv_saved; return st == GGML_STATUS_ABORTED ? 2 : -4; }
+    chain_steps = n_steps; chain_t_launch = t2;
+    if (defer_wait) return 0;                                   // the caller overlaps host work, then collects with chain_wait()
+    return chain_wait(ids);
+}
+int Model::chain_wait(std::vector<int32_t> & ids) {
+    if (chain_steps <= 0) return -1;
+    const double t3a = now_us();
     be->synchronize();
     const double t3 = now_us();
-    g.t_issue_us += t3a - t2; g.t_wait_us += t3 - t3a;
-    if (st != GGML_STATUS_SUCCESS) { kv = kv_saved; return st == GGML_STATUS_ABORTED ? 2 : -4; }
+    gctx->t_wait_us += t3 - t3a;
     const int32_t * p = (const int32_t *) ids_stage.data();
-    ids.assign(p, p + n_steps);
+    ids.assign(p, p + chain_steps);
     logits.clear(); hidden.clear(); argmax_ids.clear(); n_outputs = 0; out_ids.clear();
-    t_build_us += t1 - t0; t_upload_us += t2 - t1; t_compute_us += t3 - t2; n_decode++;
+    t_compute_us += t3 - chain_t_launch; n_decode++;
+    chain_steps = 0;
     return 0;
 }
 

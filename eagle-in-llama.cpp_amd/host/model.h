@@ -100,17 +100,32 @@ struct Model {
     static Model * create_synthetic(mh::Backend * be, const ModelConfig & cfg, const SynthOptions & opt, const Model * target /* for eagle */);
     ~Model();
     // llama_decode / llama_decode_draft: 0 ok, 1 no KV slot, <0 error (R/src/llama.cpp:9610-9617)
+    struct Cut { int node_end; ggml_tensor * t; };          // tensor parallel: partial sums to all-reduce, and where the graph is cut
     int decode(const Batch & batch, bool want_hidden);
+    // first half of decode() for a batch whose token ids are not known yet (only its shape is read): KV slots, graph, allocation, masks.
+    // A following decode() with the same shape only uploads and launches; any other call drops the preparation (KV cells given back).
+    int decode_prepare(const Batch & shape);
+    void decode_abandon();
+    struct Pending {
+        bool valid = false; Batch shape; int T = 0, n_kv = 0; bool tp = false, head_here = true, packed = false, want_logits = true; size_t span = 0;
+        std::vector<Cut> cuts; KVCache kv_saved;
+        ggml_tensor * inp_embd = nullptr, * inp_hidd = nullptr, * inp_pos = nullptr, * kq_mask = nullptr, * inp_out = nullptr;
+        ggml_tensor * result_norm = nullptr, * result_output = nullptr, * result_argmax = nullptr;
+    };
     // EAGLE head only, greedy: `n_steps` autoregressive draft steps as ONE graph (device-resident hand-off).  Step 0 is
     // `first` (accepted tokens + target features from the host); step j >= 1 feeds the device-side arg-max token of step j-1
     // (GGML_OP_ARGMAX -> GET_ROWS on a device copy of token_embd) and its result_norm row straight back in.  One upload, one
     // synchronize, n_steps ints come back.  Returns 0 and fills `ids`; 1 when the KV cache has no room (caller falls back).
-    int decode_chain(const Batch & first, int n_steps, std::vector<int32_t> & ids);
+    // defer_wait: return right after the launch; chain_wait() synchronises and collects the ids (the driver prepares the verification
+    // batch in between)
+    int decode_chain(const Batch & first, int n_steps, std::vector<int32_t> & ids, bool defer_wait = false);
+    int chain_wait(std::vector<int32_t> & ids);
+    int chain_steps = 0; double chain_t_launch = 0;
     const float * logits_ith(int i) const;      // by batch index, like llama_get_logits_ith
     const float * hidden_ith(int i) const;
     size_t matmul_weight_bytes() const { return weight_bytes; }
 
-    struct Cut { int node_end; ggml_tensor * t; };          // tensor parallel: partial sums to all-reduce, and where the graph is cut
+    Pending pend;
     struct StepIO { ggml_tensor * embd, * hidd, * pos, * mask, * out_ids; int T, n_outputs, n_kv, kv_head; };
     void build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<Cut> * cuts,
                        ggml_tensor *& result_norm, ggml_tensor *& result_output, ggml_tensor *& result_argmax);
