@@ -54,7 +54,7 @@ def test_folded_norm_is_materialised(ea, gpu, tname, T):
     the graph view finds it (graph.cpp reader counting)."""
     t = QTYPES[tname]
     rng = np.random.default_rng(5)
-    rows, k = 256, 4096
+    rows, k = (256, 4096) if T != 6 else (64, 8192)          # k = 8192: two super-blocks per wave in the norm prologue (70B width)
     w = qdata.random_blocks(t, rows, k, rng)
     x = (rng.standard_normal((T, k)) * 3).astype(np.float32)
     nw = rng.standard_normal(k).astype(np.float32)
