@@ -19,7 +19,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "lib")
-PLUGIN_PATH = os.path.join(LIB, "libggml-mi355x.so")
+PLUGIN_PATH = os.environ.get("EAGLE_MI355X_PLUGIN") or os.path.join(LIB, "libggml-mi355x.so")     # (override: A/B of compile-time variants)
 HOST_PATH = os.path.join(LIB, "libeagle_host.so")
 
 # ggml enums (include/ggml_abi.h)

@@ -251,6 +251,7 @@ struct member {
     int epi = EPI_F32; const ggml_tensor * out = nullptr;            // tensor that receives the result
     const ggml_tensor * res = nullptr;                                // residual (or broadcast bias row) for EPI_F32
     bool relu = false;                                                // EPI_F32: fused UNARY(RELU)
+    bool alt = false;                                                 // weight of the launch's second type (mixed-type pair, kernels_mmt.hip k_mmt2)
     const ggml_tensor * rope = nullptr;
     std::vector<int> swallowed;                                       // node indices done by this member
 };
@@ -342,15 +343,20 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
     }
     const int k = (int) w0->ne[0], T = (int) x->ne[1];
     // ---- collect siblings: later MUL_MATs with the same src1, same weight type
-    member mem[3]; int nm = 0;
+    member mem[4]; int nm = 0, nalt = 0;
     mem[nm].node = i; mem[nm].mm = t; nm++;
     const bool tiled0 = mi_ensure_tiled(t->src[0]);                       // first use re-lays the weight out (tile_layout.h); a launch is all-tiled or all row-major
+    // siblings of a second weight type (Q4_K_M / Q5_K_M: wv is Q6_K beside Q4_K|Q5_K wq, wk) ride in the same grid: ONE member at most
+    int alt_type = -1;
+    { mmvq_launch probe{}; probe.k = k; probe.act.norm = 1; if (tiled0 && mi_mmt_pair_supported(w0->type, GGML_TYPE_Q6_K, T, probe)) alt_type = GGML_TYPE_Q6_K; }
     for (int j = i + 1; j < c.n && j < i + 14 && nm < 3; ++j) {
         const ggml_tensor * u = c.g->nodes[j];
         if (c.done[j] || u->op != GGML_OP_MUL_MAT || u->src[1] != x) continue;
-        if (u->src[0]->type != w0->type || u->src[0]->ne[0] != k || u->src[0]->ne[2] != 1 || u->src[0]->ne[3] != 1 || !mi_supports_op(0, u)) continue;
+        const bool alt = u->src[0]->type != w0->type;
+        if (alt && (nalt || (int) u->src[0]->type != alt_type)) continue;
+        if (u->src[0]->ne[0] != k || u->src[0]->ne[2] != 1 || u->src[0]->ne[3] != 1 || !mi_supports_op(0, u)) continue;
         if (mi_ensure_tiled(u->src[0]) != tiled0) continue;
-        mem[nm].node = j; mem[nm].mm = u; nm++;
+        mem[nm].node = j; mem[nm].mm = u; mem[nm].alt = alt; nm++; nalt += alt;
     }
     // ---- SwiGLU: gate (this node) -> SILU -> MUL(silu, up)
     if (nm >= 2 && c.n_uses(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT)) {
@@ -359,6 +365,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
             const ggml_tensor * mul = c.g->nodes[c.last_use(silu)];
             for (int q = 1; q < nm; ++q) {
                 const ggml_tensor * up = mem[q].mm;
+                if (mem[q].alt) continue;
                 if (mul->op == GGML_OP_MUL && ((mul->src[0] == silu && mul->src[1] == up) || (mul->src[1] == silu && mul->src[0] == up)) &&
                     c.n_uses(up) == 1 && !(up->flags & GGML_TENSOR_FLAG_OUTPUT) && mi_same_shape(up, t) && is_f32(mul) && mi_is_contiguous(mul) &&
                     up->src[0]->ne[1] == w0->ne[1]) {
@@ -389,7 +396,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
     const ggml_tensor * pos = nullptr; const ggml_tensor * rope0 = nullptr;
     for (int q = 0; q < nm; ++q) {
         member m = mem[q];
-        plan_member(c, m);
+        plan_member(c, m); m.alt = mem[q].alt;
         if (m.rope) {     // all ropes of a launch must share positions and parameters
             if (rope0 && (m.rope->src[1] != rope0->src[1] || memcmp(m.rope->op_params, rope0->op_params, sizeof(int32_t)*11) != 0)) { if (q == 0) {} m.epi = EPI_F32; m.out = m.mm; m.rope = nullptr; m.swallowed.clear(); }
             else { rope0 = m.rope; pos = m.rope->src[1]; }
@@ -416,15 +423,21 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
         if (clash) { mi_op_concat(st, x); ap.src.X = (const float *) x->data; ap.src.xs = x->nb[1]/4; ap.src.X2 = nullptr; ap.src.xs2 = 0; ap.src.ksplit = 0; }
     }
     { static const bool dbg = getenv("GGML_MI355X_DEBUG_GROUP") != nullptr; if (dbg) MI_LOG("group at %s: %d siblings, %d kept, T=%d", t->name, nm, keep, T); }
-    mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = keep; L.swiglu = 0; L.tiled = tiled0;
+    mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = 0; L.swiglu = 0; L.tiled = tiled0;
     if (tiled0 && ap.rms) { L.act.norm_out = (float *) x->data; L.act.norm_os = x->nb[1]/4; }
-    for (int q = 0; q < keep; ++q) fill_mat(L.m[q], sel[q]);
     if (rope0) {
         L.rope.pos = (const int32_t *) pos->data; L.rope.head_dim = (int) rope0->ne[0];
         L.rope.theta_scale = powf(mi_op_f32(rope0, 5), -2.0f / mi_op_i32(rope0, 1));
         L.rope.freq_scale = mi_op_f32(rope0, 6); L.rope.attn_factor = mi_op_f32(rope0, 8);
     }
-    mi_mmvq_run(st, w0->type, T, L, ctx->act_cache, ap.rms ? (const void *) ap.rms : (const void *) x);
+    mmvq_launch LB = L; LB.act.norm_out = nullptr;                         // the second type's partition of a mixed-type launch
+    for (int q = 0; q < keep; ++q) { mmvq_launch & D = sel[q].alt ? LB : L; fill_mat(D.m[D.n_mat++], sel[q]); }
+    const void * key = ap.rms ? (const void *) ap.rms : (const void *) x;
+    if (LB.n_mat && L.n_mat && mi_mmt_pair_supported(w0->type, alt_type, T, L)) mi_mmt_run_pair(st, w0->type, alt_type, T, L, LB);
+    else {       // (the hoisted second type as a launch of its own when the activation source does not suit the in-kernel quantiser)
+        if (L.n_mat)  mi_mmvq_run(st, w0->type, T, L, ctx->act_cache, key);
+        if (LB.n_mat) { LB.act.norm_out = L.n_mat ? nullptr : L.act.norm_out; mi_mmvq_run(st, alt_type, T, LB, ctx->act_cache, key); }
+    }
     for (int q = 0; q < keep; ++q) { c.done[sel[q].node] = 1; for (int s : sel[q].swallowed) c.done[s] = 1; }
     return true;
 }

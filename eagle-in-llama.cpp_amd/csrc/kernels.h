@@ -52,6 +52,10 @@ bool mi_mmq_inline_quant(int type, int T, const mmvq_launch & L);      // the ke
 void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L);
 // tiled-layout kernel (kernels_mmt.hip): any token count, in-kernel activation quantiser for small T*k
 void mi_mmt_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L, mi_act_cache * cache, const void * key);
+// two launches over the same activations with weights of two types (Q4_K | Q5_K, then Q6_K) as one grid; <= 8 tokens, in-kernel quantiser
+bool mi_mmt_pair_supported(int typeA, int typeB, int T, const mmvq_launch & LA);
+void mi_mmt_run_pair(hipStream_t st, int typeA, int typeB, int T, const mmvq_launch & LA, const mmvq_launch & LB);
+void mi_prof_add_bytes(double bytes);                                   // profile hooks: more algorithmic bytes for the launch just recorded
 double mi_launch_bytes(const mmvq_launch & L, int T, bool dual);
 // HIP-event profile hooks around a mat-vec launch (bench.py roofline): begin returns a record index or -1 when off
 int  mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual);

@@ -288,8 +288,9 @@ __device__ unsigned long long * g_mmt_stamps = nullptr;
 template <bool STAMP> __device__ __forceinline__ void mmt_stamp(unsigned long long * base, int idx, int lane) {
     if constexpr (STAMP) { if (lane == 0 && base) base[idx] = __builtin_amdgcn_s_memrealtime(); }
 }
-template <int TYPE, bool DUAL, bool PF, int TG, int NW, bool STAMP = false>
-__global__ void __launch_bounds__(NW*WAVE) k_mmt(const mmvq_launch L, const int T, const int nbuf, const int launch_id) {
+// the kernel body: block `bid` of `nblk` (k_mmt: the whole grid; k_mmt2: one of the two partitions of a mixed-type launch)
+template <int TYPE, bool DUAL, bool PF, int TG, int NW, bool STAMP>
+__device__ __forceinline__ void mmt_body(const mmvq_launch & L, const int T, const int nbuf, const int launch_id, const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int NM = DUAL ? 2 : 1;
@@ -320,7 +321,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmt(const mmvq_launch L, const int 
     auto unit_ptr = [&](int u) -> const char * { return (DUAL ? tp[u & 1] : tp[0]) + (size_t) unit_of(u) * TILE; };
 
     mq_tfrag<TYPE> fa, fb;          // fb unused without PF
-    int grp = blockIdx.x, mi = 0, row0 = 0;
+    int grp = bid, mi = 0, row0 = 0;
     if (grp < total) set_rows(grp, mi, row0);
     auto prefetch = [&]() {          // the first tiles are in flight across the prologue
         if (grp < total) {
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmt(const mmvq_launch L, const int 
         }
         if (first) mmt_stamp<STAMP>(stp, 3, lane);                 // first group's units done (weights arrived + MFMA work)
         // next group's first tiles go out before this group's reduction / epilogue
-        const int cmi = mi, crow0 = row0, gn = grp + gridDim.x;
+        const int cmi = mi, crow0 = row0, gn = grp + nblk;
         if (gn < total) {
             set_rows(gn, mi, row0);
             if (nu > 0) fa.load(unit_ptr(0), lane, 0);
@@ -434,6 +435,18 @@ __global__ void __launch_bounds__(NW*WAVE) k_mmt(const mmvq_launch L, const int 
     }
     mmt_stamp<STAMP>(stp, 6, lane);
 }
+template <int TYPE, bool DUAL, bool PF, int TG, int NW, bool STAMP = false>
+__global__ void __launch_bounds__(NW*WAVE) k_mmt(const mmvq_launch L, const int T, const int nbuf, const int launch_id) {
+    mmt_body<TYPE, DUAL, PF, TG, NW, STAMP>(L, T, nbuf, launch_id, blockIdx.x, gridDim.x);
+}
+// Two launches that read the same activations but hold weights of different types (Q4_K_M: wq | wk are Q4_K, wv is Q6_K in half of the
+// layers) as ONE grid: blocks [0, gridA) run launch A's body, the rest launch B's -- each block builds only its own type's activation
+// image, registers are the maximum of the two bodies, and a transformer layer stays at five launches instead of six.
+template <int TA, int TB, bool PFA, bool PFB>
+__global__ void __launch_bounds__(16*WAVE) k_mmt2(const mmvq_launch LA, const mmvq_launch LB, const int T, const int nbuf, const int gridA) {
+    if ((int) blockIdx.x < gridA) mmt_body<TA, false, PFA, 1, 16, false>(LA, T, nbuf, 0, blockIdx.x, gridA);
+    else                          mmt_body<TB, false, PFB, 1, 16, false>(LB, T, nbuf, 0, blockIdx.x - gridA, gridDim.x - gridA);
+}
 
 // ---------------------------------------------------------------- host side
 static int device_cus() {
@@ -466,6 +479,7 @@ extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_mmt_st
     HIP_CHECK(hipMemcpy(out, g_stamp_host_ptr, n * 8, hipMemcpyDeviceToHost));
     return (int) n;
 }
+static bool mmt_dual_pf() { static const bool v = getenv("GGML_MI355X_MMT_DUAL_PF") != nullptr; return v; }      // A/B: double-buffered fragments in the gate|up launch
 static int mmt_nbuf() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_NBUF"); return e ? atoi(e) : 2; }(); return v; }
 
 template <int TYPE, bool DUAL, bool PF, int TG> static void mmt_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
@@ -500,7 +514,7 @@ template <int TYPE> static void mmt_launch_type(hipStream_t st, int T, const mmv
     constexpr bool PF = TYPE != GGML_TYPE_Q6_K && TYPE != GGML_TYPE_Q8_0 && TYPE != GGML_TYPE_Q4_0;      // wide fragments: single-buffered (128 VGPRs = 4 waves/SIMD)
     const int tg = (T + 7) / 8;
     MI_ASSERT(tg >= 1 && tg <= (L.swiglu ? 2 : 3));
-    if (L.swiglu) { if (tg == 1) mmt_launch_one<TYPE, true, false, 1>(st, T, L); else mmt_launch_one<TYPE, true, false, 2>(st, T, L); }
+    if (L.swiglu) { if (tg == 1) { if (PF && mmt_dual_pf()) mmt_launch_one<TYPE, true, true, 1>(st, T, L); else mmt_launch_one<TYPE, true, false, 1>(st, T, L); } else mmt_launch_one<TYPE, true, false, 2>(st, T, L); }
     else if (tg == 1) mmt_launch_one<TYPE, false, PF, 1>(st, T, L);
     else if (tg == 2) mmt_launch_one<TYPE, false, PF, 2>(st, T, L);
     else              mmt_launch_one<TYPE, false, PF, 3>(st, T, L);
@@ -595,8 +609,8 @@ __global__ void __launch_bounds__(1024) k_mmt_bb(const mmvq_launch L, const int 
     };
     mq_tfrag<TYPE> fa, fb;
     load_tile(0);
-    fa.load(tp, lane, 0);
-    if (nun > 1) fb.load(tp + TILE, lane, 0);
+    fa.template load<false>(tp, lane, 0);
+    if (nun > 1) fb.template load<false>(tp + TILE, lane, 0);
     store_tile(smem, 0);
     __syncthreads();
     float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
@@ -610,13 +624,13 @@ __global__ void __launch_bounds__(1024) k_mmt_bb(const mmvq_launch L, const int 
             const int u = 2*st;
             const mq_act A = { (const int8_t *) cur + 8*tg*BB_LDQ, BB_LDQ, (const float *)(cur + 32*BB_LDQ) + 8*tg*DN, cur + 32*BB_LDQ + 32*DN*4 + 8*tg*32, DN, T - tok_w };
             if (mine) mq_proc<TYPE, 1>::run(fa, A, 0, lane, acc);
-            if (u + 2 < nun) fa.load(tp + (size_t)(u + 2)*TILE, lane, 0);
+            if (u + 2 < nun) fa.template load<false>(tp + (size_t)(u + 2)*TILE, lane, 0);
         }
         if (2*st + 1 < nun) {
             const int u = 2*st + 1; const char * c1 = cur + BUF;
             const mq_act A = { (const int8_t *) c1 + 8*tg*BB_LDQ, BB_LDQ, (const float *)(c1 + 32*BB_LDQ) + 8*tg*DN, c1 + 32*BB_LDQ + 32*DN*4 + 8*tg*32, DN, T - tok_w };
             if (mine) mq_proc<TYPE, 1>::run(fb, A, 0, lane, acc);
-            if (u + 2 < nun) fb.load(tp + (size_t)(u + 2)*TILE, lane, 0);
+            if (u + 2 < nun) fb.template load<false>(tp + (size_t)(u + 2)*TILE, lane, 0);
         }
         if (st + 1 < nsteps) store_tile(smem + ((st + 1) & 1)*2*BUF, st + 1);
         __syncthreads();
@@ -685,6 +699,32 @@ static const char * mmt_image(hipStream_t st, int type, int T, int t0, const mmv
     return cache->pool + (size_t) hit * cache->slot_bytes;
 }
 
+static bool mmt_pair_off() { static const bool v = getenv("GGML_MI355X_MMT_NO_PAIR") != nullptr; return v; }
+bool mi_mmt_pair_supported(int typeA, int typeB, int T, const mmvq_launch & LA) {
+    if (mmt_pair_off() || T < 1 || T > 8 || typeB != GGML_TYPE_Q6_K || !(typeA == GGML_TYPE_Q4_K || typeA == GGML_TYPE_Q5_K)) return false;
+    if (!mmt_inline_quant(T, LA)) return false;                       // both bodies quantise in their prologue (same activations, same k)
+    return mmt_lds_bytes(T, LA.k, false, false, 1) <= 158*1024;
+}
+template <int TA> static void mmt_pair_launch(hipStream_t st, int T, const mmvq_launch & LA, const mmvq_launch & LB) {
+    const int nbuf = (mmt_nbuf() >= 2 && mmt_lds_bytes(T, LA.k, false, false, 2) <= 160*1024) ? 2 : 1;
+    const size_t lds = mmt_lds_bytes(T, LA.k, false, false, nbuf);
+    double bA = 0, bB = 0; int gA = 0, gB = 0;
+    for (int i = 0; i < LA.n_mat; ++i) { bA += (double) LA.m[i].rows * LA.m[i].row_bytes; gA += LA.m[i].rows / 16; }
+    for (int i = 0; i < LB.n_mat; ++i) { bB += (double) LB.m[i].rows * LB.m[i].row_bytes; gB += LB.m[i].rows / 16; }
+    const int cus = device_cus();
+    int gridA = (int)(cus * bA / (bA + bB) + 0.5); if (gridA < 1) gridA = 1; if (gridA > cus - 1) gridA = cus - 1; if (gridA > gA) gridA = gA;
+    int gridB = cus - gridA; if (gridB > gB) gridB = gB;
+    auto fn = k_mmt2<TA, GGML_TYPE_Q6_K, true, false>;
+    ensure_attr((const void *) fn);
+    const int pa = mi_prof_begin(st, LA, T, false);                    // accounted as one launch: the bytes of both
+    fn<<<gridA + gridB, 16*WAVE, lds, st>>>(LA, LB, T, nbuf, gridA);
+    mi_prof_end(st, pa);
+    mi_prof_add_bytes(mi_launch_bytes(LB, T, false) - (double) T * LB.k * 4);      // B's weights and outputs; the activations were counted once
+}
+void mi_mmt_run_pair(hipStream_t st, int typeA, int typeB, int T, const mmvq_launch & LA, const mmvq_launch & LB) {
+    MI_ASSERT(typeB == GGML_TYPE_Q6_K && LA.tiled && LB.tiled && LA.k == LB.k && !LA.swiglu && !LB.swiglu && !LA.act.pre && !LB.act.pre);
+    if (typeA == GGML_TYPE_Q4_K) mmt_pair_launch<GGML_TYPE_Q4_K>(st, T, LA, LB); else mmt_pair_launch<GGML_TYPE_Q5_K>(st, T, LA, LB);
+}
 void mi_mmt_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_act_cache * cache, const void * key) {
     MI_ASSERT(L0.tiled && cache && cache->pool && L0.k % 256 == 0);
     const int tile = mi_tile_bytes(type);

@@ -516,6 +516,11 @@ int mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual) {
     std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(r);
     return (int) g_prof.size() - 1;
 }
+void mi_prof_add_bytes(double bytes) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_count_on) g_count_bytes += bytes;
+    if (g_prof_on && !g_prof.empty()) g_prof.back().bytes += bytes;
+}
 void mi_prof_end(hipStream_t st, int idx) {
     if (idx < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);

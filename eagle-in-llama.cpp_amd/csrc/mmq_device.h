@@ -104,28 +104,32 @@ template <> struct mq_frag<GGML_TYPE_Q4_0> {          // a unit = 8 blocks of 18
 
 // ---- the same fragments from the TILED layout (tile_layout.h): `t` = base of the 16-row x 1-unit tile; every load is an aligned
 // 16-byte piece of a 1 KiB (or 256 / 512 B) run that the 64 lanes of the wave fetch together
+// NT: the mat-vec kernels stream every weight tile exactly once per launch (one CU, one read): requested non-temporally they do not
+// allocate in L2 / MALL and the stream runs ~6 % faster end to end (profiles/r02_ab_nt_weights.txt); the big-batch GEMM, whose four
+// token quarters share a tile through L2, keeps the default policy
+template <bool NT> __device__ __forceinline__ i32x4 ldw(const i32x4 * p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
 template <int TYPE> struct mq_tfrag;
 template <> struct mq_tfrag<GGML_TYPE_Q4_K> {
     static constexpr int TILE = 2304;
     i32x4 hdr, qs[2];
-    __device__ __forceinline__ void load(const char * t, int lane, int) {
-        hdr = *(const i32x4 *)(t + 16*(lane & 15)); qs[0] = *(const i32x4 *)(t + 256 + 16*lane); qs[1] = *(const i32x4 *)(t + 1280 + 16*lane);
+    template <bool NT = true> __device__ __forceinline__ void load(const char * t, int lane, int) {
+        hdr = ldw<NT>((const i32x4 *)(t + 16*(lane & 15))); qs[0] = ldw<NT>((const i32x4 *)(t + 256 + 16*lane)); qs[1] = ldw<NT>((const i32x4 *)(t + 1280 + 16*lane));
     }
 };
 template <> struct mq_tfrag<GGML_TYPE_Q5_K> {
     static constexpr int TILE = 2816;
     i32x4 hdr, qh, qs[2];
-    __device__ __forceinline__ void load(const char * t, int lane, int) {
-        hdr = *(const i32x4 *)(t + 16*(lane & 15)); qh = *(const i32x4 *)(t + 256 + 16*((lane & 15) + 16*((lane >> 4) & 1)));
-        qs[0] = *(const i32x4 *)(t + 768 + 16*lane); qs[1] = *(const i32x4 *)(t + 1792 + 16*lane);
+    template <bool NT = true> __device__ __forceinline__ void load(const char * t, int lane, int) {
+        hdr = ldw<NT>((const i32x4 *)(t + 16*(lane & 15))); qh = ldw<NT>((const i32x4 *)(t + 256 + 16*((lane & 15) + 16*((lane >> 4) & 1))));
+        qs[0] = ldw<NT>((const i32x4 *)(t + 768 + 16*lane)); qs[1] = ldw<NT>((const i32x4 *)(t + 1792 + 16*lane));
     }
 };
 template <> struct mq_tfrag<GGML_TYPE_Q6_K> {
     static constexpr int TILE = 3360;
     i32x4 ql[2], qh, sc; int dh;
-    __device__ __forceinline__ void load(const char * t, int lane, int) {
-        ql[0] = *(const i32x4 *)(t + 16*lane); ql[1] = *(const i32x4 *)(t + 1024 + 16*lane); qh = *(const i32x4 *)(t + 2048 + 16*lane);
-        sc = *(const i32x4 *)(t + 3072 + 16*(lane & 15)); dh = *(const uint16_t *)(t + 3328 + 2*(lane & 15));
+    template <bool NT = true> __device__ __forceinline__ void load(const char * t, int lane, int) {
+        ql[0] = ldw<NT>((const i32x4 *)(t + 16*lane)); ql[1] = ldw<NT>((const i32x4 *)(t + 1024 + 16*lane)); qh = ldw<NT>((const i32x4 *)(t + 2048 + 16*lane));
+        sc = ldw<NT>((const i32x4 *)(t + 3072 + 16*(lane & 15))); dh = *(const uint16_t *)(t + 3328 + 2*(lane & 15));
     }
     __device__ __forceinline__ i32x4 get_ql(int nn) const { return ql[nn]; }
     __device__ __forceinline__ i32x4 get_qh() const { return qh; }
@@ -134,10 +138,10 @@ template <> struct mq_tfrag<GGML_TYPE_Q6_K> {
 template <> struct mq_tfrag<GGML_TYPE_Q8_0> {          // k % 256 == 0: every unit has its eight blocks
     static constexpr int TILE = 4352;
     i32x4 q[4]; int dh[4];
-    __device__ __forceinline__ void load(const char * t, int lane, int) {
+    template <bool NT = true> __device__ __forceinline__ void load(const char * t, int lane, int) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) q[a] = *(const i32x4 *)(t + 1024*a + 16*lane);
-        const i32x4 d = *(const i32x4 *)(t + 4096 + 16*(lane & 15));                 // the eight f16 block scales of this lane's row
+        for (int a = 0; a < 4; ++a) q[a] = ldw<NT>((const i32x4 *)(t + 1024*a + 16*lane));
+        const i32x4 d = ldw<NT>((const i32x4 *)(t + 4096 + 16*(lane & 15)));                 // the eight f16 block scales of this lane's row
         const int hi = (lane >> 5) & 1;                                               // block 2a + (kq>>1): halfword hi of dword a
 #pragma unroll
         for (int a = 0; a < 4; ++a) dh[a] = ((uint32_t) d[a] >> (16*hi)) & 0xffff;
@@ -147,11 +151,11 @@ template <> struct mq_tfrag<GGML_TYPE_Q8_0> {          // k % 256 == 0: every un
 template <> struct mq_tfrag<GGML_TYPE_Q4_0> {
     static constexpr int TILE = 2304;
     i32x4 q[4]; int dh[4];
-    __device__ __forceinline__ void load(const char * t, int lane, int) {
+    template <bool NT = true> __device__ __forceinline__ void load(const char * t, int lane, int) {
         const int l32 = (lane & 15) + 16*((lane >> 5) & 1);                           // (row, kq>>1): both nibble halves read the same 16 bytes
 #pragma unroll
-        for (int a = 0; a < 4; ++a) q[a] = *(const i32x4 *)(t + 512*a + 16*l32);
-        const i32x4 d = *(const i32x4 *)(t + 2048 + 16*(lane & 15));
+        for (int a = 0; a < 4; ++a) q[a] = ldw<NT>((const i32x4 *)(t + 512*a + 16*l32));
+        const i32x4 d = ldw<NT>((const i32x4 *)(t + 2048 + 16*(lane & 15)));
         const int hi = (lane >> 5) & 1;
 #pragma unroll
         for (int a = 0; a < 4; ++a) dh[a] = ((uint32_t) d[a] >> (16*hi)) & 0xffff;
