@@ -35,6 +35,20 @@ __device__ __forceinline__ double row_sum_d(double v) {     // sum over the 16 l
 __device__ __forceinline__ float half_row_sum_f(float v) { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HMIR>(v); return v; }   // 8 lanes
 
 
+// Diagnostic build of the kernel (STAMP = true, only ever launched with GGML_MI355X_MMT_STAMPS set): lane 0 of every wave writes the 100 MHz
+// s_memrealtime clock at the phase boundaries into a debug ring (4 launches x 256 blocks x 16 waves x 8 stamps) that nothing else reads;
+// scripts/mmt_stamps.py turns it into the per-phase breakdown under profiles/.  The product instantiations contain no stamp code.
+#define MMT_NSTAMP 12
+__device__ unsigned long long * g_mmt_stamps = nullptr;
+template <bool STAMP> __device__ __forceinline__ void mmt_stamp(unsigned long long * base, int idx, int lane) {
+    if constexpr (STAMP) { if (lane == 0 && base) base[idx] = __builtin_amdgcn_s_memrealtime(); }
+}
+template <bool STAMP> struct mmt_stamper {      // handed into the quantiser: stamps 7.. (activations landed | partial sums reduced | after the norm barrier | scale known)
+    unsigned long long * base; int lane;
+    __device__ __forceinline__ void operator()(int idx) const { mmt_stamp<STAMP>(base, idx, lane); }
+    __device__ __forceinline__ void landed(int idx) const { if constexpr (STAMP) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mmt_stamp<STAMP>(base, idx, lane); } }
+};
+
 // ---- in-kernel activation quantiser (16 waves).  Lanes carry TOKENS: LG = 64, 32, 16 or 8 lanes serve one token (1, 2, <= 4, <= 8 tokens
 // per launch), lane = LG t + p, so all the tokens of a super-block are quantised by one pass of straight-line code and the cross-lane
 // steps are log2(LG) DPP / permute steps -- no readlane, no per-token loop (the wave-per-(token, super-block) form costs ~450
@@ -180,29 +194,36 @@ __device__ __forceinline__ void mt_quant_sb(const f32x4v (&x)[64/LG], const bool
 template <int TYPE, int LG>
 __device__ __forceinline__ void mt_load_sb(const act_src & a, f32x4v (&x)[64/LG], const bool tv, const int t, const int p, const int sb) {
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
-    // one base pointer per (token, super-block) -- CONCAT sources switch at a super-block boundary -- then constant offsets; lanes past the
-    // last token read token 0 (valid memory, results dropped at the stores)
-    const float * base = act_ptr(a, tv ? t : 0, sb*256) + mt_poff<Q80, LG>(p);
+    // one base pointer per (token, super-block) -- CONCAT sources switch at a super-block boundary -- then constant offsets; the lanes past
+    // the last token are masked off: the vector memory pipe is paid per active lane (64 B / clock / CU), idle token slots are not free
+    if (tv) {
+        const float * base = act_ptr(a, t, sb*256) + mt_poff<Q80, LG>(p);
 #pragma unroll
-    for (int i = 0; i < 64/LG; ++i) x[i] = *(const f32x4v *)(base + mt_eoff<Q80, LG>(i));
+        for (int i = 0; i < 64/LG; ++i) x[i] = *(const f32x4v *)(base + mt_eoff<Q80, LG>(i));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 64/LG; ++i) x[i] = (f32x4v){ 0.f, 0.f, 0.f, 0.f };
+    }
 }
-template <int TYPE, int LG, int NSB, class PFN>
+template <int TYPE, int LG, int NSB, class PFN, class STP>
 __device__ __forceinline__ void mt_norm_quant(const act_src & a, const int T, const int k, const int nun, const int nsb, const int ldq,
-                                              int8_t * lq, float * ldy, char * lrec, double * rd, const int lane, const int wave, PFN prefetch) {
+                                              int8_t * lq, float * ldy, char * lrec, double * rd, const int lane, const int wave, PFN prefetch, const int pfpos, STP stp) {
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int NF = 64/LG;
     const int t = lane / LG, p = lane % LG;
     const bool tv = t < T;
-    f32x4v xv[NSB][NF], wv[NF];
+    f32x4v xv[NSB][NF], wraw;
     double ss = 0.0;
 #pragma unroll
     for (int c = 0; c < NSB; ++c) if (wave + 16*c < nun) mt_load_sb<TYPE, LG>(a, xv[c], tv, t, p, wave + 16*c);
-    if (NSB == 1 && a.norm_w && wave < nun) {
-        const float * wb = a.norm_w + wave*256 + mt_poff<Q80, LG>(p);
-#pragma unroll
-        for (int i = 0; i < NF; ++i) wv[i] = *(const f32x4v *)(wb + mt_eoff<Q80, LG>(i));
-    }
-    prefetch();
+    // norm weights of this wave's super-block (one super-block per wave: k <= 4096, the usual case): ONE coalesced 1 KiB request, lane l
+    // taking floats 4l..4l+3, handed to the token groups through the wave's 1 KiB of LDS behind the partial sums -- every token group
+    // fetching its own copy would be LG-fold traffic through the vector memory pipe, in the prologue's critical path
+    const bool wlds = NSB == 1 && a.norm_w && wave < nun;
+    f32x4v * wst = (f32x4v *)((char *) rd + 1024) + wave*64;
+    if (wlds) wraw = *(const f32x4v *)(a.norm_w + wave*256 + 4*lane);
+    stp.landed(7);
+    if (pfpos == 0) prefetch();
 #pragma unroll
     for (int c = 0; c < NSB; ++c) {
         if (wave + 16*c < nun) {
@@ -211,24 +232,33 @@ __device__ __forceinline__ void mt_norm_quant(const act_src & a, const int T, co
         }
     }
     ss = grp_sum_d<LG>(ss);
-    if (p == 0) rd[t*16 + wave] = ss;
+    if (p == 0 && tv) rd[t*16 + wave] = ss;
+    if (wlds) wst[lane] = wraw;
+    stp(8);
+    if (pfpos == 1) prefetch();
     __syncthreads();
+    stp(9);
     // the 16 wave partials of this lane's token: spread over the first 16 / 8 lanes of the group, then the same group sum
     double tot = 0.0;
-    if (LG >= 16) { if (p < 16) tot = rd[t*16 + p]; }
-    else tot = rd[t*16 + p] + rd[t*16 + p + 8];
+    if (tv) {
+        if (LG >= 16) { if (p < 16) tot = rd[t*16 + p]; }
+        else tot = rd[t*16 + p] + rd[t*16 + p + 8];
+    }
     tot = grp_sum_d<LG>(tot);
     const float mean = (float)(tot / (double) k);
     const float s1 = 1.0f / sqrtf(mean + a.eps);
+    stp(10);
+    if (pfpos >= 2) prefetch();
 #pragma unroll
     for (int c = 0; c < NSB; ++c) {
         const int sb = wave + 16*c;
         if (sb < nun) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) {
-                const int e = sb*256 + mt_poff<Q80, LG>(p) + mt_eoff<Q80, LG>(i);
+                const int fi = Q80 ? NF*p + i : p + LG*i;                    // float4 of the super-block this register holds
+                const int e = sb*256 + 4*fi;
                 f32x4v v = xv[c][i] * s1;
-                if (a.norm_w) v *= (NSB == 1) ? wv[i] : *(const f32x4v *)(a.norm_w + e);
+                if (a.norm_w) v *= (NSB == 1) ? wst[fi] : *(const f32x4v *)(a.norm_w + e);
                 if (a.norm_out && blockIdx.x == 0 && tv) *(f32x4v *)(a.norm_out + (size_t) t*a.norm_os + e) = v;
                 xv[c][i] = v;
             }
@@ -239,9 +269,9 @@ __device__ __forceinline__ void mt_norm_quant(const act_src & a, const int T, co
 // `prefetch` issues the block's first weight-tile loads.  It runs right AFTER the first activation loads: vmcnt retires in issue order, so
 // activations requested behind the (HBM-cold) weight tiles would wait for them; this way the L2-warm activations come back first and
 // the quantiser's arithmetic overlaps the weight latency.
-template <int TYPE, int LG, class PFN>
+template <int TYPE, int LG, class PFN, class STP>
 __device__ __forceinline__ void mt_quantise_lg(const act_src & a, const int T, const int k, const int nun, const int nsb, const int ldq,
-                                               int8_t * lq, float * ldy, char * lrec, double * rd /* LDS [8][16] */, const int lane, const int wave, PFN prefetch) {
+                                               int8_t * lq, float * ldy, char * lrec, double * rd /* LDS [8][16] + 16 KiB */, const int lane, const int wave, PFN prefetch, const int pfpos, STP stp) {
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int NF = 64/LG;
     const int t = lane / LG, p = lane % LG;
@@ -250,25 +280,28 @@ __device__ __forceinline__ void mt_quantise_lg(const act_src & a, const int T, c
         // ggml_compute_forward_rms_norm_f32 (R/ggml/src/ggml-cpu/ggml-cpu.c:7098-7144): sum of x*x (float products) in double,
         // mean = (float)(sum / k), scale = 1/sqrtf(mean + eps); then MUL by the norm weight.  k <= 8192 here: two super-blocks per wave at
         // most; with one (k <= 4096, the usual case) the norm weights are requested together with the activations, ahead of the barrier.
-        if (nun <= 16) mt_norm_quant<TYPE, LG, 1>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch);
-        else           mt_norm_quant<TYPE, LG, 2>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch);
+        if (nun <= 16) mt_norm_quant<TYPE, LG, 1>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
+        else           mt_norm_quant<TYPE, LG, 2>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
     } else {
         f32x4v x[NF];
         if (wave < nun) mt_load_sb<TYPE, LG>(a, x, tv, t, p, wave);
-        prefetch();
+        stp.landed(7);
+        if (pfpos == 0) prefetch();
         for (int sb = wave; sb < nun; sb += 16) {
             if (sb != wave) mt_load_sb<TYPE, LG>(a, x, tv, t, p, sb);
             mt_quant_sb<TYPE, LG>(x, tv, t, p, sb, ldq, nsb, lq, ldy, lrec);
+            if (pfpos == 1 && sb == wave) prefetch();
         }
+        if (pfpos >= 2 || (pfpos == 1 && wave >= nun)) prefetch();
     }
 }
-template <int TYPE, class PFN>
+template <int TYPE, class PFN, class STP>
 __device__ __forceinline__ void mt_quantise(const act_src & a, const int T, const int k, const int nun, const int nsb, const int ldq,
-                                            int8_t * lq, float * ldy, char * lrec, double * rd, const int lane, const int wave, PFN prefetch) {
-    if (T == 1)      mt_quantise_lg<TYPE, 64>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch);
-    else if (T == 2) mt_quantise_lg<TYPE, 32>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch);
-    else if (T <= 4) mt_quantise_lg<TYPE, 16>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch);
-    else             mt_quantise_lg<TYPE, 8>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch);
+                                            int8_t * lq, float * ldy, char * lrec, double * rd, const int lane, const int wave, PFN prefetch, const int pfpos, STP stp) {
+    if (T == 1)      mt_quantise_lg<TYPE, 64>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
+    else if (T == 2) mt_quantise_lg<TYPE, 32>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
+    else if (T <= 4) mt_quantise_lg<TYPE, 16>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
+    else             mt_quantise_lg<TYPE, 8>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
 }
 
 static inline size_t mmt_img_bytes(int T, int k, bool q80) {
@@ -277,21 +310,15 @@ static inline size_t mmt_img_bytes(int T, int k, bool q80) {
 }
 static inline int mmt_nw(int T) { return T <= 8 ? 16 : 8; }             // one token group: 16 waves (128 VGPRs); 2-3 groups need 256 VGPRs: 8 waves, two blocks per CU
 static inline size_t mmt_lds_bytes(int T, int k, bool dual, bool q80, int nbuf) {
-    return mmt_img_bytes(T, k, q80) + (size_t) nbuf * (dual ? 2 : 1) * mmt_nw(T) * MT_RLD * 16;
+    const size_t red = (size_t) nbuf * (dual ? 2 : 1) * mmt_nw(T) * MT_RLD * 16;
+    return mmt_img_bytes(T, k, q80) + (red > 17408 ? red : 17408);      // the quantiser's scratch shares the reduction buffers: 1 KiB of partial sums + 16 KiB of norm weights
 }
 
-// Diagnostic build of the kernel (STAMP = true, only ever launched with GGML_MI355X_MMT_STAMPS set): lane 0 of every wave writes the 100 MHz
-// s_memrealtime clock at the phase boundaries into a debug ring (4 launches x 256 blocks x 16 waves x 8 stamps) that nothing else reads;
-// scripts/mmt_stamps.py turns it into the per-phase breakdown under profiles/.  The product instantiations contain no stamp code.
-#define MMT_NSTAMP 8
-__device__ unsigned long long * g_mmt_stamps = nullptr;
-template <bool STAMP> __device__ __forceinline__ void mmt_stamp(unsigned long long * base, int idx, int lane) {
-    if constexpr (STAMP) { if (lane == 0 && base) base[idx] = __builtin_amdgcn_s_memrealtime(); }
-}
 // the kernel body: block `bid` of `nblk` (k_mmt: the whole grid; k_mmt2: one of the two partitions of a mixed-type launch)
 template <int TYPE, bool DUAL, bool PF, int TG, int NW, bool STAMP>
-__device__ __forceinline__ void mmt_body(const mmvq_launch & L, const int T, const int nbuf, const int launch_id, const int bid, const int nblk) {
+__device__ __forceinline__ void mmt_body(const mmvq_launch & L, const int T, const int nbuf_knob, const int launch_id, const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nbuf = nbuf_knob & 0xff, pfpos = nbuf_knob >> 8;      // pfpos: where the prologue issues the first weight tiles (GGML_MI355X_MMT_PFPOS)
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int NM = DUAL ? 2 : 1;
     constexpr int TILE = mq_tfrag<TYPE>::TILE;
@@ -342,7 +369,7 @@ __device__ __forceinline__ void mmt_body(const mmvq_launch & L, const int T, con
             for (int c = tid; c < T*nsb*2; c += nthr) ((i32x4 *) lrec)[c] = ld16(sr + (size_t) c*16);
         }
     } else if constexpr (NW == 16) {
-        mt_quantise<TYPE>(L.act, T, k, nun, nsb, ldq, lq, ldy, lrec, (double *) red, lane, wave, prefetch);
+        mt_quantise<TYPE>(L.act, T, k, nun, nsb, ldq, lq, ldy, lrec, (double *) red, lane, wave, prefetch, pfpos, mmt_stamper<STAMP>{ stp, lane });
     }
     mmt_stamp<STAMP>(stp, 1, lane);                                 // this wave's share of the activation image is in LDS
     __syncthreads();
@@ -480,6 +507,7 @@ extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_mmt_st
     return (int) n;
 }
 static bool mmt_dual_pf() { static const bool v = getenv("GGML_MI355X_MMT_DUAL_PF") != nullptr; return v; }      // A/B: double-buffered fragments in the gate|up launch
+static int mmt_pfpos() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_PFPOS"); return e ? atoi(e) : 0; }(); return v; }   // A/B: 0 behind the activation loads | 1 behind the partial sums | 2 once the norm scale is known
 static int mmt_nbuf() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_NBUF"); return e ? atoi(e) : 2; }(); return v; }
 
 template <int TYPE, bool DUAL, bool PF, int TG> static void mmt_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
@@ -498,7 +526,7 @@ template <int TYPE, bool DUAL, bool PF, int TG> static void mmt_launch_one(hipSt
             auto sfn = k_mmt<TYPE, DUAL, PF, TG, NW, true>;
             ensure_attr((const void *) sfn);
             const int sgrid = total < device_cus() ? total : device_cus();
-            sfn<<<sgrid, NW*WAVE, lds, st>>>(L, T, nbuf, launch_id++);
+            sfn<<<sgrid, NW*WAVE, lds, st>>>(L, T, nbuf | (mmt_pfpos() << 8), launch_id++);
             return;
         }
     }
@@ -507,7 +535,7 @@ template <int TYPE, bool DUAL, bool PF, int TG> static void mmt_launch_one(hipSt
     const int slots = device_cus() * (NW == 16 ? 1 : ((2*lds <= 160*1024) ? 2 : 1));
     const int grid = total < slots ? total : slots;
     const int pi = mi_prof_begin(st, L, T, DUAL);
-    fn<<<grid, NW*WAVE, lds, st>>>(L, T, nbuf, 0);
+    fn<<<grid, NW*WAVE, lds, st>>>(L, T, nbuf | (mmt_pfpos() << 8), 0);
     mi_prof_end(st, pi);
 }
 template <int TYPE> static void mmt_launch_type(hipStream_t st, int T, const mmvq_launch & L) {
@@ -717,7 +745,7 @@ template <int TA> static void mmt_pair_launch(hipStream_t st, int T, const mmvq_
     auto fn = k_mmt2<TA, GGML_TYPE_Q6_K, true, false>;
     ensure_attr((const void *) fn);
     const int pa = mi_prof_begin(st, LA, T, false);                    // accounted as one launch: the bytes of both
-    fn<<<gridA + gridB, 16*WAVE, lds, st>>>(LA, LB, T, nbuf, gridA);
+    fn<<<gridA + gridB, 16*WAVE, lds, st>>>(LA, LB, T, nbuf | (mmt_pfpos() << 8), gridA);
     mi_prof_end(st, pa);
     mi_prof_add_bytes(mi_launch_bytes(LB, T, false) - (double) T * LB.k * 4);      // B's weights and outputs; the activations were counted once
 }

@@ -29,10 +29,11 @@ for w in ws: g.set(w, blk)
 g.set(nw, np.ones(k, np.float32))
 for xi in xs: g.set(xi, rng.standard_normal((T, k)).astype(np.float32))
 g.compute(); g.compute()
-n = 4 * 256 * 16 * 8
+NS = 12
+n = 4 * 256 * 16 * NS
 buf = (C.c_uint64 * n)()
 assert lib.ggml_backend_mi355x_mmt_stamps(buf) == n
-st = np.frombuffer(buf, dtype=np.uint64).reshape(4, 256, 16, 8).astype(np.int64)
+st = np.frombuffer(buf, dtype=np.uint64).reshape(4, 256, 16, NS).astype(np.int64)
 # the last four launches of the graph sit in the ring; order them by entry time
 order = np.argsort([st[i, :, :, 0][st[i, :, :, 0] > 0].min() for i in range(4)])
 print(f"q4_K rows {rows} k {k} T {T} mode {mode}: stamps in us relative to the first wave of the launch (min / median / max over waves)")
@@ -45,6 +46,10 @@ for i in order:
     for j in range(7):
         v = (s[:, :, j][valid] - t0) / 100.0
         line.append("%s %.2f/%.2f/%.2f" % (names[j], v.min(), np.median(v), v.max()))
+        if j == 0:      # inside the quantiser (stamp build only: the activation loads are waited for before the weight prefetch goes out)
+            for jj, nm in ((7, "activations landed"), (8, "partial sums parked"), (9, "after norm barrier"), (10, "norm scale known")):
+                vv = s[:, :, jj][valid]
+                if (vv > 0).any(): vv = (vv[vv > 0] - t0) / 100.0; line.append("%s %.2f/%.2f/%.2f" % (nm, vv.min(), np.median(vv), vv.max()))
     gap = "" if prev_exit is None else "  [gap from previous launch's last exit to this first entry: %.2f us]" % ((t0 - prev_exit) / 100.0)
     print(" | ".join(line) + gap)
     prev_exit = s[:, :, 6][valid].max()
