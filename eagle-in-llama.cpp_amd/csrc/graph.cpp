@@ -251,6 +251,7 @@ struct member {
     int epi = EPI_F32; const ggml_tensor * out = nullptr;            // tensor that receives the result
     const ggml_tensor * res = nullptr;                                // residual (or broadcast bias row) for EPI_F32
     bool relu = false;                                                // EPI_F32: fused UNARY(RELU)
+    const ggml_tensor * ids = nullptr;                                // EPI_F32 with res: out[j] = mm[ids[j]] + res[ids[j]] (the last layer's GET_ROWS pair + ADD)
     bool alt = false;                                                 // weight of the launch's second type (mixed-type pair, kernels_mmt.hip k_mmt2)
     const ggml_tensor * rope = nullptr;
     std::vector<int> swallowed;                                       // node indices done by this member
@@ -264,11 +265,28 @@ static bool rope_fusable(const ggml_tensor * r, const ggml_tensor * mm) {
     return true;
 }
 // follow mm's result: [RESHAPE] -> ROPE -> (CPY to f16 cache)?  |  [TRANSPOSE] -> CPY f16  |  ADD residual  |  plain
-static void plan_member(const gctx & c, member & m) {
+static bool rowsel_fuse_on() { static const bool v = getenv("GGML_MI355X_NO_ROWSEL_FUSE") == nullptr; return v; }     // A/B: output-row selection / arg-max row fetch fused
+static void plan_member(const gctx & c, member & m, bool allow_ids) {
     const ggml_tensor * mm = m.mm;
-    m.epi = EPI_F32; m.out = mm; m.res = nullptr; m.relu = false; m.rope = nullptr; m.swallowed.clear();
+    m.epi = EPI_F32; m.out = mm; m.res = nullptr; m.relu = false; m.rope = nullptr; m.ids = nullptr; m.swallowed.clear();
     if ((mm->flags & GGML_TENSOR_FLAG_OUTPUT) || c.n_uses(mm) != 1) return;
     const ggml_tensor * c1 = c.g->nodes[c.last_use(mm)];
+    // the last layer keeps only the rows that produce outputs (R/src/llama.cpp build_llama / build_eagle: cur = get_rows(cur, inp_out_ids);
+    // inpSA = get_rows(inpSA, inp_out_ids); ffn_inp = add(cur, inpSA)): three nodes right behind the output projection, done by its epilogue
+    if (allow_ids && rowsel_fuse_on() && c1->op == GGML_OP_GET_ROWS && c1->src[0] == mm && c.idx(c1) == m.node + 1 && m.node + 3 < c.n && c.n_uses(c1) == 1 && !(c1->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+        const ggml_tensor * ids = c1->src[1], * g2 = c.g->nodes[m.node + 2], * ad = c.g->nodes[m.node + 3];
+        const ggml_tensor * other = g2->src[0];
+        if (ids->type == GGML_TYPE_I32 && ids->ne[1] == 1 && ids->ne[2] == 1 && ids->ne[3] == 1 && ids->nb[0] == 4 && ids->ne[0] <= mm->ne[1] &&
+            g2->op == GGML_OP_GET_ROWS && g2->src[1] == ids && c.n_uses(g2) == 1 && !(g2->flags & GGML_TENSOR_FLAG_OUTPUT) &&
+            other && is_f32(other) && other->nb[0] == 4 && mi_same_shape(other, mm) && other != mm &&
+            ad->op == GGML_OP_ADD && ((ad->src[0] == c1 && ad->src[1] == g2) || (ad->src[0] == g2 && ad->src[1] == c1)) &&
+            is_f32(ad) && ad->nb[0] == 4 && mi_same_shape(ad, c1) && mi_same_shape(g2, c1) && c1->ne[0] == mm->ne[0] && c1->ne[2] == 1 && c1->ne[3] == 1 &&
+            !overlap(ad->data, mi_nbytes(ad), other->data, mi_nbytes(other))) {
+            m.res = other; m.out = ad; m.ids = ids;
+            m.swallowed.push_back(m.node + 1); m.swallowed.push_back(m.node + 2); m.swallowed.push_back(m.node + 3);
+            return;
+        }
+    }
     // optional reshape
     const ggml_tensor * v = c1; std::vector<int> sw;
     if (v->op == GGML_OP_RESHAPE && v->src[0] == mm && c.n_uses(v) == 1 && !(v->flags & GGML_TENSOR_FLAG_OUTPUT)) { sw.push_back(c.idx(v)); v = c.g->nodes[c.last_use(v)]; }
@@ -312,10 +330,11 @@ static void plan_member(const gctx & c, member & m) {
 }
 static void fill_mat(mmvq_mat & M, const member & m) {
     const ggml_tensor * w = m.mm->src[0];
-    M.W = (const char *) w->data; M.row_bytes = w->nb[1]; M.rows = (int) w->ne[1]; M.epi = m.epi; M.res = nullptr; M.r_tok = 0; M.relu = m.relu ? 1 : 0;
+    M.W = (const char *) w->data; M.row_bytes = w->nb[1]; M.rows = (int) w->ne[1]; M.epi = m.epi; M.res = nullptr; M.r_tok = 0; M.relu = m.relu ? 1 : 0; M.ids = nullptr; M.n_ids = 0;
     M.out = (char *) m.out->data;
     switch (m.epi) {
-        case EPI_F32:      M.o_row = 4; M.o_tok = m.out->nb[1]; if (m.res) { M.res = (const float *) m.res->data; M.r_tok = mi_nrows(m.res) == 1 ? 0 : m.res->nb[1]/4; } break;
+        case EPI_F32:      M.o_row = 4; M.o_tok = m.out->nb[1]; if (m.res) { M.res = (const float *) m.res->data; M.r_tok = mi_nrows(m.res) == 1 ? 0 : m.res->nb[1]/4; }
+                           if (m.ids) { M.ids = (const int32_t *) m.ids->data; M.n_ids = (int) m.ids->ne[0]; } break;
         case EPI_ROPE_F32: M.o_row = 4; M.o_tok = (int64_t) w->ne[1] * 4; break;                         // rope out is contiguous [d, heads, T]
         case EPI_ROPE_F16: M.o_row = 2; M.o_tok = (int64_t) w->ne[1] * 2; break;                         // contiguous f16 slice
         case EPI_F16:      M.o_row = m.out->nb[1]; M.o_tok = 2; break;                                   // out [T, rows]: token fastest
@@ -396,10 +415,18 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
     const ggml_tensor * pos = nullptr; const ggml_tensor * rope0 = nullptr;
     for (int q = 0; q < nm; ++q) {
         member m = mem[q];
-        plan_member(c, m); m.alt = mem[q].alt;
+        plan_member(c, m, tiled0 && T <= 8); m.alt = mem[q].alt;      // (row selection in the epilogue: single-pass tiled launches only)
         if (m.rope) {     // all ropes of a launch must share positions and parameters
             if (rope0 && (m.rope->src[1] != rope0->src[1] || memcmp(m.rope->op_params, rope0->op_params, sizeof(int32_t)*11) != 0)) { if (q == 0) {} m.epi = EPI_F32; m.out = m.mm; m.rope = nullptr; m.swallowed.clear(); }
             else { rope0 = m.rope; pos = m.rope->src[1]; }
+        }
+        if (q == 0 && m.out != m.mm) {
+            // the first member's fused tail writes a LATER node's buffer while other blocks still read the activations: ggml-alloc may have
+            // given that node the activations' own memory (free once this node has run) -- then the tail stays unfused
+            const size_t nb = mi_nbytes(m.out);
+            if (overlap(m.out->data, nb, ap.src.X, (size_t) T * ap.src.xs * 4) || (ap.src.X2 && overlap(m.out->data, nb, ap.src.X2, (size_t) T * ap.src.xs2 * 4))) {
+                m.epi = EPI_F32; m.out = m.mm; m.res = nullptr; m.relu = false; m.rope = nullptr; m.ids = nullptr; m.swallowed.clear();
+            }
         }
         if (q > 0) {
             // hoisting: this member's write moves from its own position (or its CPY's) up to node i
@@ -534,7 +561,13 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
             case GGML_OP_CONT: case GGML_OP_DUP: mi_op_cpy(st, t->src[0], t); break;
             case GGML_OP_CONCAT:   if (fuse && can_defer_concat(c, i)) { c.done[i] = 2; break; } mi_op_concat(st, t); break;
             case GGML_OP_GET_ROWS: mi_op_get_rows(st, t); break;
-            case GGML_OP_ARGMAX:   mi_op_argmax(st, t); break;
+            case GGML_OP_ARGMAX: {
+                // GET_ROWS(table, this arg-max) as the very next node (the draft chain's token -> embedding hand-off): one launch
+                const ggml_tensor * gr = (fuse && rowsel_fuse_on() && i + 1 < c.n && !c.done[i + 1]) ? c.g->nodes[i + 1] : nullptr;
+                if (gr && gr->op == GGML_OP_GET_ROWS && mi_argmax_rows_supported(t, gr) && !overlap(gr->data, mi_nbytes(gr), t->src[0]->data, mi_nbytes(t->src[0])) &&
+                    !overlap(gr->data, mi_nbytes(gr), t->data, mi_nbytes(t))) { mi_op_argmax(st, t, gr); c.done[i + 1] = 1; }
+                else mi_op_argmax(st, t);
+            } break;
             case GGML_OP_FLASH_ATTN_EXT: { mi_attn_args fa; if (!mi_flash_attn_args(t, fa)) { MI_LOG("flash_attn_ext: operands changed since supports_op"); return GGML_STATUS_FAILED; } mi_op_attn_small(st, fa); } break;
             case GGML_OP_ROPE:     mi_op_rope(st, t); break;
             case GGML_OP_SOFT_MAX: mi_op_soft_max(st, t); break;

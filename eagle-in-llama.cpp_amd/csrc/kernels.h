@@ -12,7 +12,8 @@ void mi_op_scale    (hipStream_t st, const ggml_tensor * dst);
 void mi_op_cpy      (hipStream_t st, const ggml_tensor * src, const ggml_tensor * dst); // CPY CONT DUP
 void mi_op_concat   (hipStream_t st, const ggml_tensor * dst);
 void mi_op_get_rows (hipStream_t st, const ggml_tensor * dst);
-void mi_op_argmax   (hipStream_t st, const ggml_tensor * dst);
+void mi_op_argmax   (hipStream_t st, const ggml_tensor * dst, const ggml_tensor * rows = nullptr);   // rows: the GET_ROWS(table, dst) node fused in
+bool mi_argmax_rows_supported(const ggml_tensor * dst, const ggml_tensor * rows);
 void mi_op_rope     (hipStream_t st, const ggml_tensor * dst);
 void mi_op_soft_max (hipStream_t st, const ggml_tensor * dst);
 // fused SwiGLU tail: dst = silu(gate) * up   (UNARY(SILU) followed by MUL)
@@ -31,6 +32,7 @@ struct mmvq_mat {
     char * out; int64_t o_row, o_tok;   // element (row, token) is written at out + row*o_row + token*o_tok  (bytes)
     const float * res; int64_t r_tok;   // optional residual (EPI_F32): res[token*r_tok + row]; r_tok = 0 broadcasts a bias row
     int relu;                           // EPI_F32: max(x, 0) after the residual / bias (fused GGML_UNARY_OP_RELU)
+    const int32_t * ids; int n_ids;     // EPI_F32 in the tiled kernel, ids non-NULL: token t's result goes to output row j for every ids[j] == t (fused GET_ROWS(., inp_out_ids))
 };
 struct mmvq_rope { const int32_t * pos; int head_dim; float theta_scale, freq_scale, attn_factor; };
 struct mmvq_launch { act_src act; int k; int n_mat; int swiglu; mmvq_mat m[3]; mmvq_rope rope; int tiled; };   // tiled: every W is in the layout of tile_layout.h (kernels_mmt.hip)

@@ -436,7 +436,11 @@ __device__ __forceinline__ void mmt_body(const mmvq_launch & L, const int T, con
                     const float v1 = (w & 3) == 0 ? s[NM-1][0] : (w & 3) == 1 ? s[NM-1][1] : (w & 3) == 2 ? s[NM-1][2] : s[NM-1][3];
                     if (act) *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = (v0 / (1.0f + expf(-v0))) * v1;
                 } else if (M.epi == EPI_F32) {
-                    if (act) { float o = v0; if (M.res) o += M.res[(size_t) tok*M.r_tok + row]; if (M.relu) o = o > 0.f ? o : 0.f; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = o; }
+                    if (act) {
+                        float o = v0; if (M.res) o += M.res[(size_t) tok*M.r_tok + row]; if (M.relu) o = o > 0.f ? o : 0.f;
+                        if (!M.ids) *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = o;
+                        else for (int j = 0; j < M.n_ids; ++j) if (M.ids[j] == tok) *(float *)(M.out + (size_t) row*M.o_row + (size_t) j*M.o_tok) = o;      // output rows that select this token
+                    }
                 } else if (M.epi == EPI_F16) {
                     if (act) *(__half *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = __float2half_rn(v0);
                 } else {   // RoPE (mode NORM) on the row pair (2p, 2p+1) = quads q, q^1 = lanes l, l^NW; theta by the reference's float recurrence (ggml_rope_cache_init)
@@ -507,7 +511,7 @@ extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_mmt_st
     return (int) n;
 }
 static bool mmt_dual_pf() { static const bool v = getenv("GGML_MI355X_MMT_DUAL_PF") != nullptr; return v; }      // A/B: double-buffered fragments in the gate|up launch
-static int mmt_pfpos() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_PFPOS"); return e ? atoi(e) : 0; }(); return v; }   // A/B: 0 behind the activation loads | 1 behind the partial sums | 2 once the norm scale is known
+static int mmt_pfpos() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_PFPOS"); return e ? atoi(e) : 2; }(); return v; }   // 0 behind the activation loads | 1 behind the partial sums | 2 once the norm scale is known
 static int mmt_nbuf() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_NBUF"); return e ? atoi(e) : 2; }(); return v; }
 
 template <int TYPE, bool DUAL, bool PF, int TG> static void mmt_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
@@ -762,7 +766,7 @@ void mi_mmt_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_a
     // k too long for the LDS image at the wanted tokens per pass (ffn_down at > 8 tokens, k = 28672 at >= 5 tokens): k-chunks of whole
     // units, every later chunk adding to the output through the residual input.  Plain outputs only (the row norm needs the whole row).
     const int Tw = Ttot >= 24 ? 24 : (Ttot >= 16 ? 16 : (Ttot > 8 ? 8 : Ttot));
-    const bool plain = L0.n_mat == 1 && !swiglu && L0.m[0].epi == EPI_F32 && !L0.m[0].relu && !L0.act.norm && !L0.act.X2;
+    const bool plain = L0.n_mat == 1 && !swiglu && L0.m[0].epi == EPI_F32 && !L0.m[0].relu && !L0.m[0].ids && !L0.act.norm && !L0.act.X2;
     if (plain && Ttot >= mmt_bb_min_tokens()) {
         // one pass over the weights for the whole batch (a3); token passes only when the batch's int8 image outgrows a scratch slot
         int tpass = Ttot;
@@ -801,6 +805,7 @@ void mi_mmt_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_a
         }
     }
     MI_ASSERT(tmax >= 1);
+    for (int i = 0; i < L0.n_mat; ++i) MI_ASSERT(!L0.m[i].ids || Ttot <= tmax);      // row selection indexes whole-launch tokens: one pass only
     for (int t0 = 0; t0 < Ttot; t0 += tmax) {
         const int T = (Ttot - t0) < tmax ? (Ttot - t0) : tmax;
         mmvq_launch L = L0;

@@ -261,7 +261,11 @@ void mi_op_get_rows(hipStream_t st, const ggml_tensor * dst) {
 
 // ------------------------------------------------------------------ ARGMAX (f32 rows -> i32): first index of the largest value,
 // like ggml_vec_argmax_f32 (R/ggml/src/ggml-cpu/vec.h).  Greedy draft / verify steps fetch 4 bytes per token instead of a logits row.
-__global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, int32_t * __restrict__ dst, int64_t ne0, int64_t nb1) {
+// `tab` non-NULL: the block also writes row `argmax` of a f16 / f32 table as floats (GET_ROWS(table, ARGMAX(x)) right behind: the greedy
+// draft chain's token -> embedding hand-off, R/examples/eagle: the next step's input is the embedding of the token just picked)
+template <typename TS>
+__global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, int32_t * __restrict__ dst, int64_t ne0, int64_t nb1,
+                                                 const char * __restrict__ tab, int64_t tab_nb1, float * __restrict__ rows, int64_t rows_nb1, int64_t row_len) {
     const float * row = (const float *)(x + (int64_t) blockIdx.x * nb1);
     float best = -INFINITY; int bi = 0x7fffffff;
     if ((ne0 & 3) == 0 && (((uintptr_t) row) & 15) == 0) {      // 16-byte loads, four of them in flight per lane (a 32000-entry logits row: two rounds)
@@ -292,13 +296,31 @@ __global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, in
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
         dst[blockIdx.x] = bi;
+        si[0] = bi;
+    }
+    if (tab) {
+        __syncthreads();
+        const TS * src = (const TS *)(tab + (int64_t) si[0] * tab_nb1);
+        float * out = (float *)((char *) rows + (int64_t) blockIdx.x * rows_nb1);
+        for (int64_t i = threadIdx.x; i < row_len; i += 1024) out[i] = cvt<TS, float>(src[i]);
     }
 }
-void mi_op_argmax(hipStream_t st, const ggml_tensor * dst) {
+// ARGMAX, optionally with the GET_ROWS that consumes it (`rows` = that node: table f16 / f32 [row_len, n], indices = dst, result f32 [row_len, rows of x])
+bool mi_argmax_rows_supported(const ggml_tensor * dst, const ggml_tensor * rows) {
+    const ggml_tensor * tab = rows->src[0], * a = dst->src[0];
+    if (rows->op != GGML_OP_GET_ROWS || rows->src[1] != dst || rows->type != GGML_TYPE_F32) return false;
+    if (!(tab->type == GGML_TYPE_F16 || tab->type == GGML_TYPE_F32) || tab->ne[2] != 1 || tab->ne[3] != 1 || tab->nb[0] != (tab->type == GGML_TYPE_F16 ? 2u : 4u)) return false;
+    if (a->ne[2] != 1 || a->ne[3] != 1 || tab->ne[1] < a->ne[0] || rows->ne[0] != tab->ne[0] || rows->ne[1] != a->ne[1] || rows->ne[2] != 1 || rows->ne[3] != 1 || rows->nb[0] != 4) return false;
+    return true;
+}
+void mi_op_argmax(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * rows) {
     const ggml_tensor * a = dst->src[0];
-    const int64_t rows = mi_nrows(a);
-    if (rows == 0) return;
-    k_argmax<<<(unsigned) rows, 1024, 0, st>>>((const char *) a->data, (int32_t *) dst->data, a->ne[0], a->nb[1]);
+    const int64_t n = mi_nrows(a);
+    if (n == 0) return;
+    if (!rows) { k_argmax<float><<<(unsigned) n, 1024, 0, st>>>((const char *) a->data, (int32_t *) dst->data, a->ne[0], a->nb[1], nullptr, 0, nullptr, 0, 0); return; }
+    const ggml_tensor * tab = rows->src[0];
+    if (tab->type == GGML_TYPE_F16) k_argmax<__half><<<(unsigned) n, 1024, 0, st>>>((const char *) a->data, (int32_t *) dst->data, a->ne[0], a->nb[1], (const char *) tab->data, tab->nb[1], (float *) rows->data, rows->nb[1], tab->ne[0]);
+    else                            k_argmax<float><<<(unsigned) n, 1024, 0, st>>>((const char *) a->data, (int32_t *) dst->data, a->ne[0], a->nb[1], (const char *) tab->data, tab->nb[1], (float *) rows->data, rows->nb[1], tab->ne[0]);
 }
 
 // ------------------------------------------------------------------ ROPE (mode NORM and NEOX, f32)

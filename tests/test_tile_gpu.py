@@ -122,3 +122,45 @@ def test_big_batch_one_pass_kernel_full_7b_rows(ea, gpu, tname):
             g.compute()
             got = g.get(out).reshape(T, rows)[:, sel]
             assert rel(got, want + (0 if r is None else r[:, sel])) < 2e-5, (tname, rows, k, T, r is not None)
+
+
+@pytest.mark.parametrize("tname", ["q4_K", "q6_K", "q8_0"])
+@pytest.mark.parametrize("ids", [[0], [4, 1, 5], [0, 1, 2, 3, 4, 5], [5, 5, 2]])
+def test_output_row_selection_in_the_epilogue(ea, gpu, tname, ids):
+    """The last layer's cur = get_rows(wo x, inp_out_ids); inpSA = get_rows(inpSA, inp_out_ids); add(cur, inpSA)
+    (R/src/llama.cpp build_llama / build_eagle) runs inside the output projection's epilogue (graph.cpp plan_member, M.ids)."""
+    t = QTYPES[tname]
+    rng = np.random.default_rng(77)
+    rows, k, T = 256, 1024, 6
+    ids = [i for i in ids if i < T]
+    w = qdata.random_blocks(t, rows, k, rng)
+    x = rng.standard_normal((T, k)).astype(np.float32)
+    r = rng.standard_normal((T, rows)).astype(np.float32)
+    g = ea.Graph(gpu, ea.USAGE_WEIGHTS)
+    a, b, res, ix = g.tensor(t, k, rows), g.tensor(ea.F32, k, T), g.tensor(ea.F32, rows, T), g.tensor(ea.I32, len(ids))
+    mm = g.mul_mat(a, b)
+    out = g.add(g.get_rows(mm, ix), g.get_rows(res, ix))
+    g.alloc(); g.set(a, w); g.set(b, x); g.set(res, r); g.set(ix, np.asarray(ids, np.int32))
+    for _ in range(2):                                                # first run re-lays the weight out, second runs on tiles
+        g.compute()
+        want = (orc.mul_mat_q(t, w, x, k, rows) + r)[ids]
+        assert rel(g.get(out).reshape(len(ids), rows), want) < 2e-5
+
+
+def test_argmax_feeds_get_rows_in_one_launch(ea, gpu):
+    """GET_ROWS(token_embd f16, ARGMAX(logits)) -- the draft chain's token -> embedding hand-off -- is one launch (graph.cpp GGML_OP_ARGMAX)."""
+    rng = np.random.default_rng(78)
+    V, E, T = 32000, 512, 3
+    logits = rng.standard_normal((T, V)).astype(np.float32)
+    logits[1, 777] = logits[1, 31999] = 9.0                           # a tie: the first index wins (ggml_vec_argmax_f32)
+    tab = rng.standard_normal((V, E)).astype(np.float16)
+    g = ea.Graph(gpu)
+    lg, tb = g.tensor(ea.F32, V, T), g.tensor(ea.F16, E, V)
+    am = g.argmax(lg)
+    rows = g.get_rows(tb, am)
+    g.alloc(); g.set(lg, logits); g.set(tb, tab)
+    g.compute()
+    want = logits.argmax(axis=1)
+    assert want[1] == 777
+    assert np.array_equal(g.get(am, np.int32).reshape(-1), want.astype(np.int32))
+    assert np.array_equal(g.get(rows).reshape(T, E), tab[want].astype(np.float32))
