@@ -208,21 +208,27 @@ static bool can_defer_norm(const gctx & c, int i) {
             x = m;
         }
     }
-    // every reader of x must be a quantised mat-mul we run with mmvq (x as src1), and `a` must outlive them all
+    // the first reader of x must be a quantised mat-mul we run with mmvq (x as src1), and `a` must outlive all such readers.  Other
+    // readers behind it (the draft chain: the next step's CONCAT reads this step's result_norm) find the tensor materialised by the
+    // TILED launches, like the host does for a wanted norm -- so with any of them every mat-mul reader has to be tiled
     const int nu = c.n_uses(x);
     if (nu < 1) return false;
-    int found = 0, last = -1;
+    auto is_mv = [&](const ggml_tensor * t) {
+        return t->op == GGML_OP_MUL_MAT && t->src[1] == x && t->src[0] != x && mi_mul_mat_q_supported_type(t->src[0]->type) && t->src[0]->ne[2] == 1 && t->src[0]->ne[3] == 1 &&
+               mi_supports_op(0, t) && !mi_tensor_is_split(t->src[0]);              // split weights run on several devices: they need the materialised tensor
+    };
+    int found = 0, last = -1, n_mv = 0;
     for (int j = c.idx(x) + 1; j < c.n && found < nu; ++j) {
         const ggml_tensor * t = c.g->nodes[j];
         bool reads = false;
         for (int s = 0; s < GGML_MAX_SRC; ++s) if (t->src[s] == x) reads = true;
         if (!reads) continue;
-        if (t->op != GGML_OP_MUL_MAT || t->src[1] != x || !mi_mul_mat_q_supported_type(t->src[0]->type) || t->src[0]->ne[2] != 1 || t->src[0]->ne[3] != 1) return false;
-        if (!mi_supports_op(0, t) || mi_tensor_is_split(t->src[0])) return false;      // split weights run on several devices: they need the materialised tensor
-        if (wanted && !mi_ensure_tiled(t->src[0])) return false;
-        found++; last = j;
+        if (is_mv(t)) { n_mv++; last = j; }
+        else { if (n_mv == 0 || is_view_op(t->op)) return false; wanted = true; }        // (a view of x could be read anywhere: not followed)
+        found++;
     }
-    if (found != nu) return false;
+    if (found != nu || n_mv == 0) return false;
+    if (wanted) for (int j = c.idx(x) + 1; j <= last; ++j) { const ggml_tensor * t = c.g->nodes[j]; if (is_mv(t) && !mi_ensure_tiled(t->src[0])) return false; }
     if (c.root_last_read(a) <= last) {
         // `a` is not read after the last consumer: its memory may already have been handed to a node in between
         std::vector<char> none(c.n, 0);

@@ -37,6 +37,8 @@ struct SpecState {
     std::vector<int32_t> drafts;
     bool fused_chain = getenv("EH_STEPWISE_DRAFT") == nullptr;
     bool device_argmax = getenv("EH_HOST_ARGMAX") == nullptr;      // EH_HOST_ARGMAX=1: fetch the logits and take the arg-max on the host like the reference's sampler
+    bool device_tokens = getenv("EH_HOST_TOKENS") == nullptr;      // EH_HOST_TOKENS=1: the drafted tokens come back to the host before the verification batch is built
+    bool chain_pending = false;                                    // the chain is still running: its tokens reach the target on the device
 };
 
 // prompt: target over all tokens (features for the draft), draft over tokens 1..n-1
@@ -88,9 +90,14 @@ static int spec_draft(SpecState & s, int n_draft, float p_min, double * st, bool
                 Batch & b = s.bt; b.clear();
                 for (int i = 0; i <= n_draft; ++i) b.add(0, s.n_past + i, 0, true);
                 s.tgt->want_logits = !s.device_argmax;
+                // greedy verification needs no token on the host either: the target gathers its embeddings from the chain's id tensor
+                // on the device (Model::dev_ids), so its pass goes out right behind the chain and ONE wait ends both
+                const bool dev = s.device_tokens && s.device_argmax && D.chain_ids && T.cfg.tp_size == 1 && T.tok_embd_device();
+                if (dev) { T.dev_ids = D.chain_ids; T.dev_table = T.tok_embd_device(); }
                 const int rp = s.tgt->decode_prepare(b);
                 s.tgt->want_logits = true;
                 (void) rp;                                     // a failed preparation is simply redone (and reported) by decode()
+                if (dev) { s.chain_pending = true; s.drafts.assign((size_t) n_draft, 0); st[ST_T_DRAFT_US] += now_us() - t0; return n_draft; }
                 const int rw = D.chain_wait(ids);
                 if (rw) return -10 + rw;
             }
@@ -133,8 +140,15 @@ static int spec_verify(SpecState & s, int32_t * out, double * st) {
     for (size_t i = 0; i < s.drafts.size(); ++i) b.add(s.drafts[i], s.n_past + 1 + (int) i, 0, true);
     T.want_logits = !s.device_argmax;
     int rc = T.decode(b, true);
-    T.want_logits = true;
+    T.want_logits = true; T.dev_ids = nullptr; T.dev_table = nullptr;
     st[ST_N_TARGET_CALLS] += 1;
+    if (s.chain_pending) {                                         // the wait inside decode() ended the chain too: collect its tokens
+        s.chain_pending = false;
+        std::vector<int32_t> ids;
+        const int rw = s.dft->chain_wait(ids);
+        if (rw) return -10 + rw;
+        s.drafts = ids;
+    }
     if (rc) return -20 - rc;
     // ---- accept (greedy)
     int m = 0, n_out = 0;

@@ -431,7 +431,8 @@ int Model::decode_prepare(const Batch & b) {
 
     mh::Ctx & g = *gctx;
     g.reset_graph();
-    P.inp_embd = g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd");
+    P.dev_tokens = dev_ids && dev_table && !cfg.eagle && !P.tp && dev_ids->ne[0] == T;
+    P.inp_embd = P.dev_tokens ? nullptr : g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd");
     P.inp_hidd = cfg.eagle ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_hidd") : nullptr;
     P.inp_pos  = g.new_tensor(GGML_TYPE_I32, T, 1, 1, 1, "inp_pos");
     const int Tpad = (T + GGML_KQ_MASK_PAD - 1) / GGML_KQ_MASK_PAD * GGML_KQ_MASK_PAD;
@@ -439,7 +440,9 @@ int Model::decode_prepare(const Batch & b) {
     P.inp_out  = g.new_tensor(GGML_TYPE_I32, n_outputs, 1, 1, 1, "inp_out_ids");
     for (ggml_tensor * t : {P.inp_embd, P.inp_hidd, P.inp_pos, P.kq_mask, P.inp_out}) if (t) t->flags |= GGML_TENSOR_FLAG_INPUT;
 
-    StepIO io{ P.inp_embd, P.inp_hidd, P.inp_pos, P.kq_mask, P.inp_out, T, n_outputs, n_kv, kv_head };
+    ggml_tensor * embd = P.inp_embd;
+    if (P.dev_tokens) embd = g.get_rows((ggml_tensor *) dev_table, (ggml_tensor *) dev_ids);      // llm_build_inp_embd's GET_ROWS branch (R/src/llama.cpp:495-503), indices already on the device
+    StepIO io{ embd, P.inp_hidd, P.inp_pos, P.kq_mask, P.inp_out, T, n_outputs, n_kv, kv_head };
     P.result_norm = nullptr; P.result_output = nullptr; P.result_argmax = nullptr;
     build_forward(g, io, P.tp, &P.cuts, P.result_norm, P.result_output, P.result_argmax);
     P.head_here = !P.tp || cfg.tp_rank == 0;                 // TP: the LM head (and the hidden-state channel) live on rank 0
@@ -451,10 +454,11 @@ int Model::decode_prepare(const Batch & b) {
     // back to back in the compute buffer: their host image is assembled in page-locked memory and goes up as ONE
     // asynchronous copy ordered before the graph (the reference issues one blocking ggml_backend_tensor_set per input).
     ggml_tensor * inputs[5] = { P.inp_embd, P.inp_hidd, P.inp_pos, P.kq_mask, P.inp_out };
-    P.span = 0; P.packed = true;
+    P.span = 0; P.packed = true; P.base = nullptr;
+    for (ggml_tensor * t : inputs) if (t && !P.base) P.base = t;
     for (ggml_tensor * t : inputs) if (t) {
-        const ptrdiff_t off = (char *) t->data - (char *) P.inp_embd->data;
-        if (t->buffer != P.inp_embd->buffer || off < 0 || (size_t) off > ((size_t) 64 << 20)) { P.packed = false; break; }
+        const ptrdiff_t off = (char *) t->data - (char *) P.base->data;
+        if (t->buffer != P.base->buffer || off < 0 || (size_t) off > ((size_t) 64 << 20)) { P.packed = false; break; }
         P.span = std::max(P.span, (size_t) off + mh::nbytes(t));
     }
     if (P.packed && P.span > stage_cap) {
@@ -462,7 +466,7 @@ int Model::decode_prepare(const Batch & b) {
         stage_cap = P.span + P.span/2 + 4096; stage_in = (char *) be->host_alloc(stage_cap);
     }
     if (P.packed) {      // shape-dependent part of the image: positions, output rows, mask
-        auto host_of = [&](ggml_tensor * t) -> char * { return stage_in + ((char *) t->data - (char *) P.inp_embd->data); };
+        auto host_of = [&](ggml_tensor * t) -> char * { return stage_in + ((char *) t->data - (char *) P.base->data); };
         memcpy(host_of(P.inp_pos), b.pos.data(), (size_t) T * 4);
         memcpy(host_of(P.inp_out), out_ids.data(), (size_t) n_outputs * 4);
         float * mask = (float *) host_of(P.kq_mask);
@@ -484,8 +488,9 @@ int Model::decode(const Batch & b, bool want_hidden) {
     const int T = b.n_tokens();
     if (T <= 0) return -1;
     if (cfg.eagle && (int) b.hidd.size() != T * cfg.n_embd) { decode_abandon(); return -2; }
-    for (int i = 0; i < T; ++i) if (b.token[i] < 0 || b.token[i] >= cfg.n_vocab) { decode_abandon(); return -6; }       // llama_decode: "invalid token" (R/src/llama.cpp:9500)
-    if (!(pend.valid && pend.want_logits == want_logits && same_shape(pend.shape, b))) {
+    const bool dev = dev_ids && dev_table && !cfg.eagle && cfg.tp_size == 1 && dev_ids->ne[0] == T;      // tokens live on the device: Batch::token is a placeholder
+    if (!dev) for (int i = 0; i < T; ++i) if (b.token[i] < 0 || b.token[i] >= cfg.n_vocab) { decode_abandon(); return -6; }       // llama_decode: "invalid token" (R/src/llama.cpp:9500)
+    if (!(pend.valid && pend.want_logits == want_logits && pend.dev_tokens == dev && same_shape(pend.shape, b))) {
         const int rc = decode_prepare(b);
         if (rc) return rc;
     }
@@ -496,11 +501,11 @@ int Model::decode(const Batch & b, bool want_hidden) {
     mh::Ctx & g = *gctx;
     static thread_local std::vector<char> unpacked;
     auto host_of = [&](ggml_tensor * t) -> char * {
-        if (P.packed) return stage_in + ((char *) t->data - (char *) P.inp_embd->data);
+        if (P.packed) return stage_in + ((char *) t->data - (char *) P.base->data);
         unpacked.resize(mh::nbytes(t)); return unpacked.data();
     };
     auto flush = [&](ggml_tensor * t, char * h) { if (!P.packed) g.set(t, h, 0, mh::nbytes(t)); };
-    {
+    if (P.inp_embd) {
         float * embd = (float *) host_of(P.inp_embd);
         for (int i = 0; i < T; ++i) { const uint16_t * src = tok_embd.data() + (size_t) b.token[i] * E; h2f_row(src, embd + (size_t) i * E, E); }
         flush(P.inp_embd, (char *) embd);
@@ -518,7 +523,7 @@ int Model::decode(const Batch & b, bool want_hidden) {
         }
         flush(P.kq_mask, (char *) mask);
     }
-    if (P.packed) g.set_async(P.inp_embd, stage_in, 0, P.span);
+    if (P.packed) g.set_async(P.base, stage_in, 0, P.span);
     const double t2 = now_us();
 
     // ---- compute, then the outputs by asynchronous copies into page-locked memory, one wait for everything
@@ -567,21 +572,26 @@ int Model::argmax_ith(int i) const {
     }
     return -1;
 }
+// device copy of token_embd (f16 [n_embd, n_vocab]), made on first use
+const ggml_tensor * Model::tok_embd_device() {
+    if (!tok_embd_dev) {
+        ectx.reset(new mh::Ctx(be)); ectx->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+        tok_embd_dev = ectx->new_tensor(GGML_TYPE_F16, cfg.n_embd, cfg.n_vocab, 1, 1, "token_embd.weight");
+        if (!ectx->alloc()) { tok_embd_dev = nullptr; ectx.reset(); return nullptr; }
+        ectx->set(tok_embd_dev, tok_embd.data(), 0, tok_embd.size() * 2);
+    }
+    return tok_embd_dev;
+}
 // ------------------------------------------------------------------ fused greedy draft chain
 int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> & ids, bool defer_wait) {
     const double t0 = now_us();
     decode_abandon();
-    ids.clear();
+    ids.clear(); chain_ids = nullptr;
     const int T0 = first.n_tokens(), E = cfg.n_embd;
     if (!cfg.eagle || cfg.tp_size > 1 || T0 <= 0 || n_steps < 1) return -1;
     if ((int) first.hidd.size() != T0 * E) return -2;
     for (int i = 0; i < T0; ++i) if (first.token[i] < 0 || first.token[i] >= cfg.n_vocab) return -6;
-    if (!tok_embd_dev) {                                       // the reference keeps token_embd on the host; the fused loop needs it next to the arg-max
-        ectx.reset(new mh::Ctx(be)); ectx->usage = GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
-        tok_embd_dev = ectx->new_tensor(GGML_TYPE_F16, E, cfg.n_vocab, 1, 1, "token_embd.weight");
-        if (!ectx->alloc()) { tok_embd_dev = nullptr; ectx.reset(); return -3; }
-        ectx->set(tok_embd_dev, tok_embd.data(), 0, tok_embd.size() * 2);
-    }
+    if (!tok_embd_device()) return -3;                         // the reference keeps token_embd on the host; the fused loop needs it next to the arg-max
     // ---- KV slots of every step (positions are known in advance: a chain)
     std::vector<Batch> bs(n_steps);
     std::vector<int> heads(n_steps);
@@ -604,6 +614,9 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     struct In { ggml_tensor * embd, * hidd, * pos, * mask, * out; int T, Tpad; };
     std::vector<In> in(n_steps);
     std::vector<ggml_tensor *> inputs;
+    // [last token of the first batch, arg-max of step 0, 1, ...]: slot 0 goes up with the inputs, every step's ARGMAX writes its slot (below)
+    chain_ids = g.new_tensor(GGML_TYPE_I32, 1 + n_steps, 1, 1, 1, "chain_ids");
+    chain_ids->flags |= GGML_TENSOR_FLAG_INPUT; inputs.push_back(chain_ids);
     for (int j = 0; j < n_steps; ++j) {
         const int T = bs[j].n_tokens(), Tpad = (T + GGML_KQ_MASK_PAD - 1) / GGML_KQ_MASK_PAD * GGML_KQ_MASK_PAD;
         in[j].T = T; in[j].Tpad = Tpad;
@@ -628,7 +641,8 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     }
     want_logits = saved_want;
     last_n_nodes = (int) g.nodes.size();
-    if (!g.alloc()) { kv = kv_saved; return -3; }
+    if (!g.alloc()) { kv = kv_saved; chain_ids = nullptr; return -3; }
+    for (int j = 0; j < n_steps; ++j) { amax[j]->data = (char *) chain_ids->data + 4*(j + 1); amax[j]->buffer = chain_ids->buffer; }      // (the slots the allocator gave them stay unused)
     const double t1 = now_us();
 
     // ---- host image of the inputs, one asynchronous copy
@@ -646,6 +660,7 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     static thread_local std::vector<char> unpacked;
     auto host_of = [&](ggml_tensor * t) -> char * { if (packed) return stage_in + ((char *) t->data - (char *) base->data); unpacked.resize(mh::nbytes(t)); return unpacked.data(); };
     auto flush = [&](ggml_tensor * t, char * h) { if (!packed) g.set(t, h, 0, mh::nbytes(t)); };
+    { char * h = host_of(chain_ids); memset(h, 0, mh::nbytes(chain_ids)); memcpy(h, &first.token[T0 - 1], 4); flush(chain_ids, h); }
     for (int j = 0; j < n_steps; ++j) {
         const Batch & b = bs[j]; const int T = in[j].T;
         if (in[j].embd) {
@@ -671,7 +686,7 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     enum ggml_status st = g.compute_async();
     const double t3a = now_us();
     if (ids_stage.size() < (size_t) n_steps) ids_stage.resize((size_t) n_steps + 64);
-    if (st == GGML_STATUS_SUCCESS) for (int j = 0; j < n_steps; ++j) g.get_async(amax[j], (int32_t *) ids_stage.data() + j, 0, 4);
+    if (st == GGML_STATUS_SUCCESS) g.get_async(chain_ids, ids_stage.data(), 4, (size_t) n_steps * 4);      // one copy: the steps' slots are contiguous
     g.t_issue_us += t3a - t2;
     t_build_us += t1 - t0; t_upload_us += t2 - t1;
     if (st != GGML_STATUS_SUCCESS) { be->synchronize(); kv = kv_saved; return st == GGML_STATUS_ABORTED ? 2 : -4; }

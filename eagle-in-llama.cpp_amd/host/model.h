@@ -110,6 +110,8 @@ struct Model {
         bool valid = false; Batch shape; int T = 0, n_kv = 0; bool tp = false, head_here = true, packed = false, want_logits = true; size_t span = 0;
         std::vector<Cut> cuts; KVCache kv_saved;
         ggml_tensor * inp_embd = nullptr, * inp_hidd = nullptr, * inp_pos = nullptr, * kq_mask = nullptr, * inp_out = nullptr;
+        ggml_tensor * base = nullptr;      // first input tensor: origin of the packed host image
+        bool dev_tokens = false;           // the embeddings are fetched on the device (dev_ids below): no inp_embd
         ggml_tensor * result_norm = nullptr, * result_output = nullptr, * result_argmax = nullptr;
     };
     // EAGLE head only, greedy: `n_steps` autoregressive draft steps as ONE graph (device-resident hand-off).  Step 0 is
@@ -121,6 +123,12 @@ struct Model {
     int decode_chain(const Batch & first, int n_steps, std::vector<int32_t> & ids, bool defer_wait = false);
     int chain_wait(std::vector<int32_t> & ids);
     int chain_steps = 0; double chain_t_launch = 0;
+    // Device-side token hand-off of the greedy chain (driver.cpp spec_round): the chain's graph keeps [first token, arg-max of step 0, 1, ...]
+    // in ONE i32 tensor; a target whose dev_ids / dev_table point at it (and at the draft's device copy of token_embd) builds its
+    // batch embeddings as GET_ROWS(dev_table, dev_ids) -- the verification pass is enqueued right behind the chain, with no host
+    // round trip for the drafted tokens in between.  decode() then ignores Batch::token (shape and positions still come from the batch).
+    ggml_tensor * chain_ids = nullptr;          // draft: valid from decode_chain() until its next graph build
+    const ggml_tensor * dev_ids = nullptr, * dev_table = nullptr;
     const float * logits_ith(int i) const;      // by batch index, like llama_get_logits_ith
     const float * hidden_ith(int i) const;
     size_t matmul_weight_bytes() const { return weight_bytes; }
@@ -131,6 +139,8 @@ struct Model {
                        ggml_tensor *& result_norm, ggml_tensor *& result_output, ggml_tensor *& result_argmax);
     std::unique_ptr<mh::Ctx> ectx;    // device copy of token_embd (f16 [n_embd, n_vocab]), created on the first decode_chain
     ggml_tensor * tok_embd_dev = nullptr;
+  public:
+    const ggml_tensor * tok_embd_device();      // device copy of token_embd, made on first use (nullptr: no memory)
 };
 
 // per-type byte size of a row

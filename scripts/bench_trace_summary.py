@@ -11,7 +11,7 @@ marks = [i for i, r in enumerate(rows) if "k_profile_mark" in r["Kernel_Name"]]
 sel = rows[marks[-2] + 1:marks[-1]]
 b = json.loads(open(bench_json).read().strip().splitlines()[-1])
 steps = b["steps"]
-MV = ("k_mmt<", "k_mmt_bb<", "k_mmq<", "k_mmvq<")
+MV = ("k_mmt<", "k_mmt2<", "k_mmt_bb<", "k_mmq<", "k_mmvq<")
 def short(n): return re.sub(r"\(.*", "", n).replace("void ", "")[:70]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in sel:
