@@ -105,7 +105,7 @@ template <> struct mq_frag<GGML_TYPE_Q4_0> {          // a unit = 8 blocks of 18
 // ---- the same fragments from the TILED layout (tile_layout.h): `t` = base of the 16-row x 1-unit tile; every load is an aligned
 // 16-byte piece of a 1 KiB (or 256 / 512 B) run that the 64 lanes of the wave fetch together
 // NT: the mat-vec kernels stream every weight tile exactly once per launch (one CU, one read): requested non-temporally they do not
-// allocate in L2 / MALL and the stream runs ~6 % faster end to end (profiles/r02_ab_nt_weights.txt); the big-batch GEMM, whose four
+// allocate in L2 / MALL and the stream runs ~6 % faster end to end (profiles/r02_ab_second_half.txt); the big-batch GEMM, whose four
 // token quarters share a tile through L2, keeps the default policy
 template <bool NT> __device__ __forceinline__ i32x4 ldw(const i32x4 * p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
 template <int TYPE> struct mq_tfrag;
