@@ -39,6 +39,7 @@ struct SpecState {
     bool device_argmax = getenv("EH_HOST_ARGMAX") == nullptr;      // EH_HOST_ARGMAX=1: fetch the logits and take the arg-max on the host like the reference's sampler
     bool device_tokens = getenv("EH_HOST_TOKENS") == nullptr;      // EH_HOST_TOKENS=1: the drafted tokens come back to the host before the verification batch is built
     bool chain_pending = false;                                    // the chain is still running: its tokens reach the target on the device
+    bool re_on_device = false;                                     // re_feat was left on the device (Model::last_norm of the target); re_tok is on the host as always
 };
 
 // prompt: target over all tokens (features for the draft), draft over tokens 1..n-1
@@ -77,10 +78,15 @@ static int spec_draft(SpecState & s, int n_draft, float p_min, double * st, bool
     Batch & d = s.bd; d.clear();
     const int nre = (int) s.re_tok.size();
     for (int i = 0; i < nre; ++i) d.add(s.re_tok[i], s.re_pos0 + i, 0, i == nre - 1);
-    d.hidd = s.re_feat;
+    const bool chain = s.fused_chain && p_min <= 0.0f && n_draft > 1 && D.cfg.tp_size == 1;
+    if (s.re_on_device && chain && T.last_norm.data && T.last_argmax.data) { D.first_feat = T.last_norm; D.first_ids = T.last_argmax; d.hidd.clear(); }
+    else {
+        if (s.re_on_device) { s.re_feat.resize((size_t) nre * E); if (T.fetch_last_hidden(s.re_feat.data(), nre)) return -9; s.re_on_device = false; }
+        d.hidd = s.re_feat;
+    }
     // greedy without a confidence cut-off: the whole chain runs as ONE graph with the token / feature hand-off on the device
     // (Model::decode_chain); EH_STEPWISE_DRAFT=1 keeps the reference's one-decode-per-step loop
-    if (s.fused_chain && p_min <= 0.0f && n_draft > 1 && D.cfg.tp_size == 1) {
+    if (chain) {
         std::vector<int32_t> ids;
         const int rc = D.decode_chain(d, n_draft, ids, defer);
         if (rc == 0) {
@@ -106,6 +112,7 @@ static int spec_draft(SpecState & s, int n_draft, float p_min, double * st, bool
             return (int) s.drafts.size();
         }
         if (rc < 0) return -10 + rc;                       // rc == 1 (no KV room for the whole chain): fall through to the stepwise loop
+        if (s.re_on_device) { s.re_feat.resize((size_t) nre * E); if (T.fetch_last_hidden(s.re_feat.data(), nre)) return -9; s.re_on_device = false; d.hidd = s.re_feat; }
     }
     // greedy without a confidence cut-off only needs the arg-max token: it is computed on the device (GGML_OP_ARGMAX appended to
     // the graph) and 4 bytes come back instead of a 128 KB logits row; p_min > 0 needs the probabilities, hence the logits
@@ -139,7 +146,9 @@ static int spec_verify(SpecState & s, int32_t * out, double * st) {
     b.add(s.id_last, s.n_past, 0, true);
     for (size_t i = 0; i < s.drafts.size(); ++i) b.add(s.drafts[i], s.n_past + 1 + (int) i, 0, true);
     T.want_logits = !s.device_argmax;
-    int rc = T.decode(b, true);
+    // the features of the accepted tokens go back to the draft on the device when the next round runs the fused chain (spec_draft)
+    const bool keep_dev = s.chain_pending && s.device_tokens;
+    int rc = T.decode(b, !keep_dev);
     T.want_logits = true; T.dev_ids = nullptr; T.dev_table = nullptr;
     st[ST_N_TARGET_CALLS] += 1;
     if (s.chain_pending) {                                         // the wait inside decode() ended the chain too: collect its tokens
@@ -161,8 +170,12 @@ static int spec_verify(SpecState & s, int32_t * out, double * st) {
     st[ST_N_ACCEPT] += m; st[ST_N_PREDICT] += n_out; st[ST_N_ITERS] += 1;
     // ---- bookkeeping: target keeps id_last + m drafts; next round re-ingests [d1..dm, bonus] with F rows 0..m
     s.re_tok.assign(out, out + n_out);
-    s.re_feat.resize((size_t) n_out * E);
-    for (int i = 0; i < n_out; ++i) memcpy(s.re_feat.data() + (size_t) i * E, T.hidden_ith(i), (size_t) E * 4);
+    s.re_on_device = keep_dev && T.last_norm.data && T.last_norm.rows >= n_out;
+    if (!s.re_on_device) {
+        s.re_feat.resize((size_t) n_out * E);
+        if (keep_dev) { if (T.fetch_last_hidden(s.re_feat.data(), n_out)) return -29; }
+        else for (int i = 0; i < n_out; ++i) memcpy(s.re_feat.data() + (size_t) i * E, T.hidden_ith(i), (size_t) E * 4);
+    }
     s.re_pos0 = s.n_past + 1;
     s.n_past += m + 1;
     T.kv.seq_rm(0, s.n_past, -1);

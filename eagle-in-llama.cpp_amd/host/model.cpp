@@ -554,7 +554,13 @@ int Model::decode(const Batch & b, bool want_hidden) {
     g.t_issue_us += t3a - t2; g.t_wait_us += t3 - t3a;
     if (st != GGML_STATUS_SUCCESS) { kv = P.kv_saved; return st == GGML_STATUS_ABORTED ? 2 : -4; }
     argmax_ids.clear();
-    if (P.head_here && P.result_argmax) { const int32_t * p = (const int32_t *) ids_stage.data(); argmax_ids.assign(p, p + n_outputs); }
+    last_norm = DevRows(); last_argmax = DevRows();
+    if (P.head_here && P.result_argmax) {
+        const int32_t * p = (const int32_t *) ids_stage.data(); argmax_ids.assign(p, p + n_outputs);
+        if (!P.tp && P.result_norm && n_outputs == T) {        // row r = batch token r
+            last_norm = DevRows{ P.result_norm->data, P.result_norm->buffer, n_outputs }; last_argmax = DevRows{ P.result_argmax->data, P.result_argmax->buffer, n_outputs };
+        }
+    }
     kv.head += T;
     if (kv.head >= kv.size) kv.head = 0;
     const double t4 = now_us();
@@ -571,6 +577,16 @@ int Model::argmax_ith(int i) const {
         return b;
     }
     return -1;
+}
+int Model::fetch_last_hidden(float * dst, int rows) {
+    if (!last_norm.data || rows > last_norm.rows) return -1;
+    ggml_tensor t; memset(&t, 0, sizeof(t));
+    t.type = GGML_TYPE_F32; t.ne[0] = cfg.n_embd; t.ne[1] = rows; t.ne[2] = t.ne[3] = 1;
+    t.nb[0] = 4; t.nb[1] = (size_t) cfg.n_embd * 4; t.nb[2] = t.nb[3] = t.nb[1] * rows;
+    t.data = last_norm.data; t.buffer = last_norm.buffer;
+    be->synchronize();
+    t.buffer->iface.get_tensor(t.buffer, &t, dst, 0, (size_t) rows * cfg.n_embd * 4);
+    return 0;
 }
 // device copy of token_embd (f16 [n_embd, n_vocab]), made on first use
 const ggml_tensor * Model::tok_embd_device() {
@@ -589,7 +605,10 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     ids.clear(); chain_ids = nullptr;
     const int T0 = first.n_tokens(), E = cfg.n_embd;
     if (!cfg.eagle || cfg.tp_size > 1 || T0 <= 0 || n_steps < 1) return -1;
-    if ((int) first.hidd.size() != T0 * E) return -2;
+    const bool dev_first = first_feat.data && first_ids.data && T0 <= first_feat.rows && T0 <= first_ids.rows;      // step 0 reads the target's rows on the device
+    const DevRows dfeat = first_feat, dids = first_ids;
+    first_feat = DevRows(); first_ids = DevRows();
+    if (!dev_first && (int) first.hidd.size() != T0 * E) return -2;
     for (int i = 0; i < T0; ++i) if (first.token[i] < 0 || first.token[i] >= cfg.n_vocab) return -6;
     if (!tok_embd_device()) return -3;                         // the reference keeps token_embd on the host; the fused loop needs it next to the arg-max
     // ---- KV slots of every step (positions are known in advance: a chain)
@@ -620,8 +639,8 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     for (int j = 0; j < n_steps; ++j) {
         const int T = bs[j].n_tokens(), Tpad = (T + GGML_KQ_MASK_PAD - 1) / GGML_KQ_MASK_PAD * GGML_KQ_MASK_PAD;
         in[j].T = T; in[j].Tpad = Tpad;
-        in[j].embd = j == 0 ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd") : nullptr;
-        in[j].hidd = j == 0 ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_hidd") : nullptr;
+        in[j].embd = j == 0 && !dev_first ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd") : nullptr;
+        in[j].hidd = j == 0 && !dev_first ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_hidd") : nullptr;
         in[j].pos  = g.new_tensor(GGML_TYPE_I32, T, 1, 1, 1, "inp_pos");
         in[j].mask = g.new_tensor(GGML_TYPE_F32, n_kv, Tpad, 1, 1, "KQ_mask");
         in[j].out  = g.new_tensor(GGML_TYPE_I32, 1, 1, 1, 1, "inp_out_ids");
@@ -631,8 +650,14 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     want_logits = false;                                        // every step ends in GGML_OP_ARGMAX
     std::vector<ggml_tensor *> amax(n_steps);
     ggml_tensor * prev_norm = nullptr;
+    ggml_tensor * dev_hidd = nullptr, * dev_tok = nullptr;
+    if (dev_first) {      // leaves over the target's memory (pre-set data: the allocator leaves them alone)
+        dev_hidd = g.new_tensor(GGML_TYPE_F32, E, T0, 1, 1, "inp_hidd"); dev_hidd->data = dfeat.data; dev_hidd->buffer = dfeat.buffer;
+        dev_tok  = g.new_tensor(GGML_TYPE_I32, T0, 1, 1, 1, "inp_tokens"); dev_tok->data = dids.data; dev_tok->buffer = dids.buffer;
+    }
     for (int j = 0; j < n_steps; ++j) {
         ggml_tensor * embd = in[j].embd, * hidd = in[j].hidd;
+        if (j == 0 && dev_first) { embd = g.get_rows(tok_embd_dev, dev_tok); hidd = dev_hidd; }
         if (j > 0) { embd = g.get_rows(tok_embd_dev, amax[j - 1]); hidd = prev_norm; }     // the hand-off never leaves the device
         StepIO io{ embd, hidd, in[j].pos, in[j].mask, in[j].out, in[j].T, 1, n_kv, heads[j] };
         ggml_tensor * rn = nullptr, * ro = nullptr, * ra = nullptr;

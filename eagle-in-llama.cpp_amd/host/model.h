@@ -128,6 +128,13 @@ struct Model {
     // batch embeddings as GET_ROWS(dev_table, dev_ids) -- the verification pass is enqueued right behind the chain, with no host
     // round trip for the drafted tokens in between.  decode() then ignores Batch::token (shape and positions still come from the batch).
     ggml_tensor * chain_ids = nullptr;          // draft: valid from decode_chain() until its next graph build
+    // ... and of the verification pass back to the chain: after a decode() with device arg-max the rows of result_norm and the arg-max ids
+    // stay where they are in the compute buffer (nothing writes it before this model's next upload, which is stream-ordered behind
+    // whatever was enqueued meanwhile).  A draft whose first_* point there reads the re-ingested tokens and features on the device.
+    struct DevRows { void * data = nullptr; ggml_backend_buffer_t buffer = nullptr; int rows = 0; };
+    DevRows last_norm, last_argmax;             // target: set by decode() (cleared when it fails or runs without the arg-max op)
+    DevRows first_feat, first_ids;              // draft: consumed by the next decode_chain() (step 0 inputs), then cleared
+    int fetch_last_hidden(float * dst, int rows);   // the same rows for a caller that needs them on the host after all
     const ggml_tensor * dev_ids = nullptr, * dev_table = nullptr;
     const float * logits_ith(int i) const;      // by batch index, like llama_get_logits_ith
     const float * hidden_ith(int i) const;
