@@ -12,6 +12,7 @@
 #include "ggml_mi355x.h"
 #include "kernels.h"
 #include <mutex>
+#include <chrono>
 #include <vector>
 #include <string>
 #include <dlfcn.h>
@@ -275,6 +276,18 @@ static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const ggml_tensor
 }
 static void be_sync(ggml_backend_t b) {
     mi_backend_ctx * c = (mi_backend_ctx *) b->context; set_device(c->device);
+    // poll the stream for up to GGML_MI355X_SYNC_SPIN us (default 4000) before falling back to the blocking wait: the wake-up of a
+    // blocked host thread is part of every decode's latency (the reference's CUDA backend spins inside cudaStreamSynchronize by default)
+    static const long spin_us = [] { const char * e = getenv("GGML_MI355X_SYNC_SPIN"); return e ? atol(e) : 4000L; }();
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) return;
+            if (q != hipErrorNotReady) { HIP_CHECK(q); return; }
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 static enum ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph * g) {

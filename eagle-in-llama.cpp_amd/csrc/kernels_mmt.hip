@@ -283,6 +283,7 @@ __device__ __forceinline__ void mt_quantise_lg(const act_src & a, const int T, c
         if (nun <= 16) mt_norm_quant<TYPE, LG, 1>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
         else           mt_norm_quant<TYPE, LG, 2>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
     } else {
+        // (keeping a second super-block of activations in flight per wave measured +-0 at k = 11008 and costs registers: not done)
         f32x4v x[NF];
         if (wave < nun) mt_load_sb<TYPE, LG>(a, x, tv, t, p, wave);
         stp.landed(7);
