@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "kernels.h"
+#include "lane_ops.h"
 #include <mutex>
 #include <cstdlib>
 
@@ -140,10 +141,10 @@ template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_at
             _Float16 * prow = ph + t*ldP;
             float mx = -INFINITY;
             for (int i = sub; i < n_kv; i += lg) mx = fmaxf(mx, row[i]);
-            for (int o = lg >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, lg));
+            mx = row_max_f(mx); if (lg == 32) mx = max_xw<16>(mx);            // 16 or 32 lanes per token: DPP row steps + one VALU lane-pair step
             double sum = 0.0;
             for (int i = sub; i < n_kv; i += lg) { const float e = (row[i] == -INFINITY) ? 0.0f : expf(row[i] - mx); row[i] = e; sum += (double) e; }
-            for (int o = lg >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, lg);
+            sum = row_sum_d(sum); if (lg == 32) sum = sum_xw<16>(sum);
             const float inv = (float)(1.0 / sum);
             for (int i = sub; i < n_kv; i += lg) prow[i] = (_Float16)(row[i] * inv);
         }

@@ -24,14 +24,6 @@
 
 #define MT_RLD 65                       // f32x4 slots per wave in a reduction buffer (64 lanes + 1: spreads the readers over the banks)
 
-__device__ __forceinline__ double row_sum_d(double v) {     // sum over the 16 lanes of a DPP row, result in every lane of the row
-    int2 p = *(int2 *) &v;
-#define DSTEP(C) { int2 q; q.x = dpp_i<C>(p.x); q.y = dpp_i<C>(p.y); v += *(double *) &q; p = *(int2 *) &v; }
-    DSTEP(DPP_XOR1) DSTEP(DPP_XOR2) DSTEP(DPP_HMIR) DSTEP(DPP_MIR)
-#undef DSTEP
-    return v;
-}
-
 __device__ __forceinline__ float half_row_sum_f(float v) { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HMIR>(v); return v; }   // 8 lanes
 
 
@@ -62,15 +54,15 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int LG> __device__ __forceinline__ float grp_max_f(float v) {           // max over the LG lanes of a token group, result in every lane
     v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_HMIR>(v));
     if (LG >= 16) v = fmaxf(v, dpp_f<DPP_MIR>(v));
-    if (LG >= 32) v = fmaxf(v, __shfl_xor(v, 16));
-    if (LG >= 64) v = fmaxf(v, __shfl_xor(v, 32));
+    if (LG >= 32) v = max_xw<16>(v);
+    if (LG >= 64) v = max_xw<32>(v);
     return v;
 }
 template <int LG> __device__ __forceinline__ int grp_min_i(int v) {
     v = min(v, dpp_i<DPP_XOR1>(v)); v = min(v, dpp_i<DPP_XOR2>(v)); v = min(v, dpp_i<DPP_HMIR>(v));
     if (LG >= 16) v = min(v, dpp_i<DPP_MIR>(v));
-    if (LG >= 32) v = min(v, __shfl_xor(v, 16));
-    if (LG >= 64) v = min(v, __shfl_xor(v, 32));
+    if (LG >= 32) v = min_xw<16>(v);
+    if (LG >= 64) v = min_xw<32>(v);
     return v;
 }
 template <int LG> __device__ __forceinline__ double grp_sum_d(double v) {
@@ -79,8 +71,8 @@ template <int LG> __device__ __forceinline__ double grp_sum_d(double v) {
     DSTEP(DPP_XOR1) DSTEP(DPP_XOR2) DSTEP(DPP_HMIR)
     if (LG >= 16) DSTEP(DPP_MIR)
 #undef DSTEP
-    if (LG >= 32) v += __shfl_xor(v, 16);
-    if (LG >= 64) v += __shfl_xor(v, 32);
+    if (LG >= 32) v = sum_xw<16>(v);
+    if (LG >= 64) v = sum_xw<32>(v);
     return v;
 }
 // max of three on one instruction (fmaxf chains go through NaN canonicalisation: 4x the instructions); operands are finite activations

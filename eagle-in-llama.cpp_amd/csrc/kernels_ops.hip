@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "kernels.h"
+#include "lane_ops.h"
 #include <math.h>
 
 #define WAVE 64
@@ -21,16 +22,10 @@ static inline dims4 mk_dims(const ggml_tensor * t) {
 }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = WAVE/2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = WAVE/2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
+// result in every lane; the order of the additions is a fixed tree (row steps, then rows, then halves)
+__device__ __forceinline__ float  wave_sum(float v)  { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HMIR>(v); v += dpp_f<DPP_MIR>(v); v = sum_xw<16>(v); return sum_xw<32>(v); }
+__device__ __forceinline__ double wave_sum(double v) { v = row_sum_d(v); v = sum_xw<16>(v); return sum_xw<32>(v); }
+__device__ __forceinline__ float  wave_max(float v)  { v = row_max_f(v); v = max_xw<16>(v); return max_xw<32>(v); }
 // block-wide reductions for blocks of NW waves (result valid in every thread)
 template <typename T, int NW> __device__ __forceinline__ T block_sum(T v, T * sh) {
     v = wave_sum(v);
@@ -285,11 +280,15 @@ __global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, in
     for (int64_t i = threadIdx.x; i < ne0; i += 1024) { const float v = row[i]; if (v > best || (v == best && (int) i < bi)) { best = v; bi = (int) i; } }
     if (bi == 0x7fffffff) bi = 0;                          // all NaN / -inf lanes fall back to index 0 like the CPU loop
     __shared__ float sv[16]; __shared__ int si[16];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-    }
+    // wave arg-max: (value, index) pairs through the DPP row steps, then the two lane-pair steps (no LDS round trips)
+#define AM_STEP(C) { const float ov = dpp_f<C>(best); const int oi = dpp_i<C>(bi); if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
+    AM_STEP(DPP_XOR1) AM_STEP(DPP_XOR2) AM_STEP(DPP_HMIR) AM_STEP(DPP_MIR)
+#undef AM_STEP
+#define AM_PAIR(W) { uint32_t va, vb, ia, ib; lane_pair<W>(__float_as_uint(best), va, vb); lane_pair<W>((uint32_t) bi, ia, ib); \
+        const float fa = __uint_as_float(va), fb = __uint_as_float(vb); \
+        if (fb > fa || (fb == fa && (int) ib < (int) ia)) { best = fb; bi = (int) ib; } else { best = fa; bi = (int) ia; } }
+    AM_PAIR(16) AM_PAIR(32)
+#undef AM_PAIR
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { sv[wave] = best; si[wave] = bi; }
     __syncthreads();

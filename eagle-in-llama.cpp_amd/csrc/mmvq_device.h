@@ -15,21 +15,11 @@ __device__ __forceinline__ int dot4(int a, int b, int c) { return __builtin_amdg
 __device__ __forceinline__ int dot16(i32x4 a, i32x4 b) {
     int s = dot4(a.x, b.x, 0); s = dot4(a.y, b.y, s); s = dot4(a.z, b.z, s); return dot4(a.w, b.w, s);
 }
-// ---- wave64 reductions on the DPP path (no LDS traffic, unlike ds_bpermute-based __shfl):
-// quad_perm xor1 / xor2, row_half_mirror, row_mirror fold a 16-lane row; the four row sums are combined through readlane.
-template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
-template <int CTRL> __device__ __forceinline__ int   dpp_i(int v)   { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-#define DPP_XOR1 0xB1      /* quad_perm [1,0,3,2] */
-#define DPP_XOR2 0x4E      /* quad_perm [2,3,0,1] */
-#define DPP_HMIR 0x141     /* row_half_mirror: lane i <-> 7-i  (acts as xor 4 once quads are uniform) */
-#define DPP_MIR  0x140     /* row_mirror:      lane i <-> 15-i (acts as xor 8 once half rows are uniform) */
-__device__ __forceinline__ float rdl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }   // readlane is an int builtin: bit-cast, never convert
-__device__ __forceinline__ float row_sum_f(float v) { v += dpp_f<DPP_XOR1>(v); v += dpp_f<DPP_XOR2>(v); v += dpp_f<DPP_HMIR>(v); v += dpp_f<DPP_MIR>(v); return v; }
+#include "lane_ops.h"
 __device__ __forceinline__ float wave_sum_f(float v) {        // result in every lane
     v = row_sum_f(v);
     return (rdl_f(v, 0) + rdl_f(v, 16)) + (rdl_f(v, 32) + rdl_f(v, 48));
 }
-__device__ __forceinline__ float row_max_f(float v) { v = fmaxf(v, dpp_f<DPP_XOR1>(v)); v = fmaxf(v, dpp_f<DPP_XOR2>(v)); v = fmaxf(v, dpp_f<DPP_HMIR>(v)); v = fmaxf(v, dpp_f<DPP_MIR>(v)); return v; }
 __device__ __forceinline__ float wave_max_f(float v) {
     v = row_max_f(v);
     return fmaxf(fmaxf(rdl_f(v, 0), rdl_f(v, 16)), fmaxf(rdl_f(v, 32), rdl_f(v, 48)));
