@@ -40,7 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N_DRAFT = 5
 PROMPT_LEN = 128
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
-MATVEC_KERNELS = ("k_mmt<", "k_mmt_bb<", "k_mmq<", "k_mmvq<")
+MATVEC_KERNELS = ("k_mmt<", "k_mmt2<", "k_mmt_bb<", "k_mmq<", "k_mmvq<")
 
 
 def load_pkg():

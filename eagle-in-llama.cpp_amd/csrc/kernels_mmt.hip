@@ -585,20 +585,27 @@ static bool mmt_inline_quant(int T, const mmvq_launch & L) {
 // block moves 9 KB of weights (HBM; the four token quarters of a row block run on one XCD and share them in L2) against 10 KB of
 // activations (L2): balanced, every CU busy, weights streamed once for the whole batch instead of once per 24 tokens.
 #define BB_LDQ 272                      // bytes per token row of an activation tile (256 + 16: conflict-free 16-byte operand reads)
-template <int TYPE>
-__global__ void __launch_bounds__(1024) k_mmt_bb(const mmvq_launch L, const int T, const int n_rq) {
+// TGW = 8-token groups one wave multiplies with a dequantised tile (1, 2 or 4): the block keeps its 64 rows x 32 tokens and runs
+// 16 / TGW waves, every weight tile being unpacked 4 / TGW times per block instead of four.  Measured on the 128-token 7B prompt
+// (scripts/prompt_time.py, profiles/r02_ab_second_half.txt): 12.7 ms at TGW = 1, 14.9 at 2, 21.7 at 4 -- the kernel lives on its 16
+// waves hiding LDS operand and MFMA latency, not on unpacking work; TGW = 1 is what runs (GGML_MI355X_MMT_BB_TGW selects the others)
+template <int TYPE, int TGW>
+__global__ void __launch_bounds__(1024 / TGW) k_mmt_bb(const mmvq_launch L, const int T, const int n_rq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int TILE = mq_tfrag<TYPE>::TILE;
+    constexpr int NT = 1024 / TGW, NTG = 4 / TGW;                    // threads; token groups of waves
     constexpr int DN = Q80 ? 8 : 1;                                  // activation scales per (token, unit)
     constexpr int BUF = 32*BB_LDQ + 32*DN*4 + (Q80 ? 0 : 32*32);     // one tile: quants | scales | split block sums
+    constexpr int NITEM = 512 + 32*DN + (Q80 ? 0 : 64);              // staging items of a tile: 16-byte quant pieces | scales | 16-byte record pieces
+    constexpr int NI = (NITEM + NT - 1) / NT;
     const int k = L.k, nun = k/256, nsb_img = Q80 ? k/32 : nun;
     const int tid = threadIdx.x, lane = tid % WAVE, wave = tid / WAVE;
     // block -> (row quad, token quarter): the quarters of one row quad get block ids 8 apart (one XCD under round-robin placement: speed only)
     const int b = blockIdx.x, nq = (T + 31) / 32;
     const int rq = (b & 7) + 8 * ((b >> 3) / nq), tq = (b >> 3) % nq;
     if (rq >= n_rq) return;
-    const int rg = wave >> 2, tg = wave & 3;
+    const int rg = wave / NTG, tg = wave % NTG;
     const mmvq_mat & M = L.m[0];
     const int row0 = rq*64 + rg*16, t0 = tq*32;
     const bool rows_ok = row0 < M.rows;                              // the last row quad may hold fewer than four groups
@@ -607,19 +614,22 @@ __global__ void __launch_bounds__(1024) k_mmt_bb(const mmvq_launch L, const int 
     const char * img = L.act.pre;
     const float * img_d = (const float *)(img + (size_t) T*k);
     const char * img_rec = Q80 ? nullptr : img + act_img_bytes(true, T, k) + (TYPE == GGML_TYPE_Q6_K ? (size_t) T*nsb_img*32 : 0);
-    // this thread's share of a tile: 16 bytes of quants (threads 0..511), one scale (next 32*DN threads), 16 bytes of block sums (next 64)
-    const int my_tok = t0 + (tid < 512 ? tid >> 4 : tid < 512 + 32*DN ? (tid - 512) / DN : (tid - 512 - 32*DN) >> 1);
-    const bool tok_ok = my_tok < T;
     // a step = two units (one barrier per 512 k): the step's two activation tiles sit side by side in one LDS buffer
-    i32x4 rq4[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}; float rd[2] = {0.f, 0.f};
+    i32x4 rq4[2][NI];
     auto load_tile = [&](int step) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int u = 2*step + j;
             if (u >= nun) break;
-            if (tid < 512) rq4[j] = tok_ok ? *(const i32x4 *)(img + (size_t) my_tok*k + u*256 + 16*(tid & 15)) : (i32x4)(0);
-            else if (tid < 512 + 32*DN) rd[j] = tok_ok ? img_d[(size_t) my_tok*nsb_img + u*DN + (tid - 512) % DN] : 0.f;
-            else if (!Q80 && tid < 512 + 32*DN + 64) rq4[j] = tok_ok ? ld16(img_rec + ((size_t) my_tok*nsb_img + u)*32 + 16*((tid - 512 - 32*DN) & 1)) : (i32x4)(0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = tid + i*NT;
+                i32x4 v = {0, 0, 0, 0};
+                if (c < 512) { const int tok = t0 + (c >> 4); if (tok < T) v = *(const i32x4 *)(img + (size_t) tok*k + u*256 + 16*(c & 15)); }
+                else if (c < 512 + 32*DN) { const int tok = t0 + (c - 512) / DN; if (tok < T) v.x = __float_as_int(img_d[(size_t) tok*nsb_img + u*DN + (c - 512) % DN]); }
+                else if (!Q80 && c < NITEM) { const int tok = t0 + ((c - 512 - 32*DN) >> 1); if (tok < T) v = ld16(img_rec + ((size_t) tok*nsb_img + u)*32 + 16*((c - 512 - 32*DN) & 1)); }
+                rq4[j][i] = v;
+            }
         }
     };
     auto store_tile = [&](char * buf0, int step) {
@@ -627,9 +637,13 @@ __global__ void __launch_bounds__(1024) k_mmt_bb(const mmvq_launch L, const int 
         for (int j = 0; j < 2; ++j) {
             if (2*step + j >= nun) break;
             char * buf = buf0 + j*BUF;
-            if (tid < 512) *(i32x4 *)(buf + (tid >> 4)*BB_LDQ + 16*(tid & 15)) = rq4[j];
-            else if (tid < 512 + 32*DN) ((float *)(buf + 32*BB_LDQ))[tid - 512] = rd[j];
-            else if (!Q80 && tid < 512 + 32*DN + 64) *(i32x4 *)(buf + 32*BB_LDQ + 32*DN*4 + (tid - 512 - 32*DN)*16) = rq4[j];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int c = tid + i*NT;
+                if (c < 512) *(i32x4 *)(buf + (c >> 4)*BB_LDQ + 16*(c & 15)) = rq4[j][i];
+                else if (c < 512 + 32*DN) ((int *)(buf + 32*BB_LDQ))[c - 512] = rq4[j][i].x;
+                else if (!Q80 && c < NITEM) *(i32x4 *)(buf + 32*BB_LDQ + 32*DN*4 + (c - 512 - 32*DN)*16) = rq4[j][i];
+            }
         }
     };
     mq_tfrag<TYPE> fa, fb;
@@ -638,8 +652,12 @@ __global__ void __launch_bounds__(1024) k_mmt_bb(const mmvq_launch L, const int 
     if (nun > 1) fb.template load<false>(tp + TILE, lane, 0);
     store_tile(smem, 0);
     __syncthreads();
-    float acc[1][4] = {{0.f, 0.f, 0.f, 0.f}};
-    const int tok_w = t0 + 8*tg;                                    // first token of this wave
+    float acc[TGW][4];
+#pragma unroll
+    for (int t = 0; t < TGW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+    const int tok_w = t0 + 8*TGW*tg;                                // first token of this wave
     const bool mine = rows_ok && tok_w < T;
     const int nsteps = (nun + 1) / 2;
     for (int st = 0; st < nsteps; ++st) {
@@ -647,32 +665,36 @@ __global__ void __launch_bounds__(1024) k_mmt_bb(const mmvq_launch L, const int 
         if (st + 1 < nsteps) load_tile(st + 1);
         {
             const int u = 2*st;
-            const mq_act A = { (const int8_t *) cur + 8*tg*BB_LDQ, BB_LDQ, (const float *)(cur + 32*BB_LDQ) + 8*tg*DN, cur + 32*BB_LDQ + 32*DN*4 + 8*tg*32, DN, T - tok_w };
-            if (mine) mq_proc<TYPE, 1>::run(fa, A, 0, lane, acc);
+            const mq_act A = { (const int8_t *) cur + 8*TGW*tg*BB_LDQ, BB_LDQ, (const float *)(cur + 32*BB_LDQ) + 8*TGW*tg*DN, cur + 32*BB_LDQ + 32*DN*4 + 8*TGW*tg*32, DN, T - tok_w };
+            if (mine) mq_proc<TYPE, TGW>::run(fa, A, 0, lane, acc);
             if (u + 2 < nun) fa.template load<false>(tp + (size_t)(u + 2)*TILE, lane, 0);
         }
         if (2*st + 1 < nun) {
             const int u = 2*st + 1; const char * c1 = cur + BUF;
-            const mq_act A = { (const int8_t *) c1 + 8*tg*BB_LDQ, BB_LDQ, (const float *)(c1 + 32*BB_LDQ) + 8*tg*DN, c1 + 32*BB_LDQ + 32*DN*4 + 8*tg*32, DN, T - tok_w };
-            if (mine) mq_proc<TYPE, 1>::run(fb, A, 0, lane, acc);
+            const mq_act A = { (const int8_t *) c1 + 8*TGW*tg*BB_LDQ, BB_LDQ, (const float *)(c1 + 32*BB_LDQ) + 8*TGW*tg*DN, c1 + 32*BB_LDQ + 32*DN*4 + 8*TGW*tg*32, DN, T - tok_w };
+            if (mine) mq_proc<TYPE, TGW>::run(fb, A, 0, lane, acc);
             if (u + 2 < nun) fb.template load<false>(tp + (size_t)(u + 2)*TILE, lane, 0);
         }
         if (st + 1 < nsteps) store_tile(smem + ((st + 1) & 1)*2*BUF, st + 1);
         __syncthreads();
     }
-    // classes (lanes l, l ^ 32) meet in registers; lanes kq < 2 hold row n, tokens tok_w + 4 kq + r
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[0][r] + __shfl_xor(acc[0][r], 32);
+    // classes (lanes l, l ^ 32) meet in registers; lanes kq < 2 hold row n, tokens tok_w + 8 t + 4 kq + r
     const int n = lane & 15, kq = lane >> 4, row = row0 + n;
-    if (mine && kq < 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tok = tok_w + 4*kq + r;
-            if (tok < T) { float o = v[r]; if (M.res) o += M.res[(size_t) tok*M.r_tok + row]; if (M.relu) o = o > 0.f ? o : 0.f; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = o; }
+    for (int t = 0; t < TGW; ++t) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = sum_xw<32>(acc[t][r]);
+        if (mine && kq < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tok = tok_w + 8*t + 4*kq + r;
+                if (tok < T) { float o = v[r]; if (M.res) o += M.res[(size_t) tok*M.r_tok + row]; if (M.relu) o = o > 0.f ? o : 0.f; *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = o; }
+            }
         }
     }
 }
+static int mmt_bb_tgw() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_BB_TGW"); const int t = e ? atoi(e) : 1; return (t == 1 || t == 2 || t == 4) ? t : 1; }(); return v; }
 template <int TYPE> static void mmt_bb_launch(hipStream_t st, int T, const mmvq_launch & L) {
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int DN = Q80 ? 8 : 1;
@@ -681,7 +703,11 @@ template <int TYPE> static void mmt_bb_launch(hipStream_t st, int T, const mmvq_
     const int n_rq = (L.m[0].rows + 63) / 64, nq = (T + 31) / 32;
     const int grid = ((n_rq + 7) / 8) * 8 * nq;
     const int pi = mi_prof_begin(st, L, T, false);
-    k_mmt_bb<TYPE><<<grid, 1024, lds, st>>>(L, T, n_rq);
+    switch (mmt_bb_tgw()) {
+        case 2:  k_mmt_bb<TYPE, 2><<<grid, 512, lds, st>>>(L, T, n_rq); break;
+        case 4:  k_mmt_bb<TYPE, 4><<<grid, 256, lds, st>>>(L, T, n_rq); break;
+        default: k_mmt_bb<TYPE, 1><<<grid, 1024, lds, st>>>(L, T, n_rq); break;
+    }
     mi_prof_end(st, pi);
 }
 static void mmt_bb_dispatch(hipStream_t st, int type, int T, const mmvq_launch & L) {
