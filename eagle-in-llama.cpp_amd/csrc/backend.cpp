@@ -274,6 +274,14 @@ static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const ggml_tensor
     HIP_CHECK(hipEventDestroy(ev));
     return true;
 }
+void mi_allow_big_lds(const void * fn) {
+    static std::mutex mu; static std::vector<std::pair<const void *, int>> done;
+    int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto & d : done) if (d.first == fn && d.second == dev) return;
+    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+    done.emplace_back(fn, dev);
+}
 static void be_sync(ggml_backend_t b) {
     mi_backend_ctx * c = (mi_backend_ctx *) b->context; set_device(c->device);
     // poll the stream for up to GGML_MI355X_SYNC_SPIN us (default 4000) before falling back to the blocking wait: the wake-up of a

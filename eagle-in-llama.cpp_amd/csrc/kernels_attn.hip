@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include "kernels.h"
+#include "mi355x_common.h"
 #include "lane_ops.h"
 #include <mutex>
 #include <cstdlib>
@@ -251,16 +252,12 @@ void mi_op_attn_small(hipStream_t st, const mi_attn_args & a) {
     int dsplit = (a.H * tiles >= 256) ? ntile/4 : ((a.H * tiles >= 128) ? ntile/2 : ntile);
     if (dsplit < 1) dsplit = 1;
     const dim3 grid(a.H, tiles, dsplit);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-        HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024));
-    });
     if (a.d == 128 && attn_stamps_on()) {
-        static std::once_flag o2; std::call_once(o2, [] { HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_small<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024)); });
+        mi_allow_big_lds((const void *) k_attn_small<128, true>);
         k_attn_small<128, true><<<grid, 256, lds, st>>>(a, tt);
         return;
     }
+    mi_allow_big_lds(a.d == 128 ? (const void *) k_attn_small<128> : (const void *) k_attn_small<64>);
     if (a.d == 128) k_attn_small<128><<<grid, 256, lds, st>>>(a, tt);
     else            k_attn_small<64><<<grid, 256, lds, st>>>(a, tt);
 }

@@ -194,7 +194,7 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_lds.find(fn);
     if (it == g_lds.end() || it->second < lds) {
-        if (lds > 48*1024) HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
+        if (lds > 48*1024) mi_allow_big_lds(fn);
         int nb = 0;
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds));
         if (getenv("GGML_MI355X_DEBUG_OCC")) fprintf(stderr, "[mi355x] occupancy fn=%p threads=%d lds=%zu -> %d blocks/CU\n", fn, threads, lds, nb);

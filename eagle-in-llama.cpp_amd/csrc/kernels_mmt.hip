@@ -237,7 +237,8 @@ __device__ __forceinline__ void mt_norm_quant(const act_src & a, const int T, co
         else tot = rd[t*16 + p] + rd[t*16 + p + 8];
     }
     tot = grp_sum_d<LG>(tot);
-    const float mean = (float)(tot / (double) k);
+    // sum / k: an exponent step when k is a power of two (4096, 8192: bit-identical to the division, a fraction of its instruction chain)
+    const float mean = (k & (k - 1)) == 0 ? (float) __builtin_ldexp(tot, -__builtin_ctz(k)) : (float)(tot / (double) k);
     const float s1 = 1.0f / sqrtf(mean + a.eps);
     stp(10);
     if (pfpos >= 2) prefetch();
@@ -264,7 +265,6 @@ __device__ __forceinline__ void mt_norm_quant(const act_src & a, const int T, co
 template <int TYPE, int LG, class PFN, class STP>
 __device__ __forceinline__ void mt_quantise_lg(const act_src & a, const int T, const int k, const int nun, const int nsb, const int ldq,
                                                int8_t * lq, float * ldy, char * lrec, double * rd /* LDS [8][16] + 16 KiB */, const int lane, const int wave, PFN prefetch, const int pfpos, STP stp) {
-    constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int NF = 64/LG;
     const int t = lane / LG, p = lane % LG;
     const bool tv = t < T;
@@ -477,13 +477,7 @@ static int device_cus() {
     static const int n = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256; return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }();
     return n;
 }
-static void ensure_attr(const void * fn) {
-    static std::mutex mu; static std::vector<const void *> done;
-    std::lock_guard<std::mutex> lk(mu);
-    for (const void * f : done) if (f == fn) return;
-    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
-    done.push_back(fn);
-}
+static void ensure_attr(const void * fn) { mi_allow_big_lds(fn); }
 static unsigned long long * g_stamp_host_ptr = nullptr;
 static bool mmt_stamps_on() {
     static const bool on = [] {

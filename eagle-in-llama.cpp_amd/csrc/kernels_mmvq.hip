@@ -426,7 +426,6 @@ void mi_quant_act(hipStream_t st, int type, int T, const act_src & a0, int k, ch
 
 // ---------------------------------------------------------------- host side
 static std::mutex g_attr_mu;
-static std::unordered_set<const void *> g_attr_done;
 static std::unordered_map<const void *, std::pair<size_t, int>> g_occ;     // kernel -> (largest LDS asked for, resident blocks per CU at that size)
 static int occupancy_blocks(const void * fn, int threads, size_t lds) {
     std::lock_guard<std::mutex> lk(g_attr_mu);
@@ -440,13 +439,7 @@ static int occupancy_blocks(const void * fn, int threads, size_t lds) {
     }
     return it->second.second;
 }
-static void ensure_lds_attr(const void * fn, size_t bytes) {
-    if (bytes <= 48*1024) return;
-    std::lock_guard<std::mutex> lk(g_attr_mu);
-    if (g_attr_done.count(fn)) return;
-    HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024));
-    g_attr_done.insert(fn);
-}
+static void ensure_lds_attr(const void * fn, size_t bytes) { if (bytes > 48*1024) mi_allow_big_lds(fn); }
 // ---- optional HIP-event profile of every mat-vec launch (bench.py roofline; off by default, zero cost when off)
 struct prof_rec { hipEvent_t a, b; double bytes; };
 static std::mutex g_prof_mu;

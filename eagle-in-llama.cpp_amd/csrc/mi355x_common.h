@@ -118,6 +118,9 @@ bool mi_is_tiled(const ggml_tensor * t);                    // t itself carries 
 bool mi_tile_eligible(const ggml_tensor * w);
 bool mi_ensure_tiled(ggml_tensor * w);                      // first MUL_MAT use: permute in place; returns whether w is tiled now
 void mi_untile(ggml_tensor * t, bool never_again);         // back to ggml's layout (t or the tensor it views)
+// hipFuncAttributeMaxDynamicSharedMemorySize for `fn` on the CURRENT device, once per (kernel, device): the attribute lives in the
+// device's code object, so a kernel first launched on device 1 (row-split buffers) needs its own call
+void mi_allow_big_lds(const void * fn);
 void mi_tile_permute(hipStream_t st, const void * src, void * dst, int type, int64_t rows, int64_t k, bool fwd);
 
 // graph.cpp
