@@ -9,7 +9,7 @@ n = 0; kib = 0.0; per = {}
 for r in csv.DictReader(open(f)):
     if r.get('Counter_Name') != 'FETCH_SIZE': continue
     name = r['Kernel_Name']
-    if not any(m in name for m in ('k_mmt<', 'k_mmt_bb<', 'k_mmq<', 'k_mmvq<')): continue
+    if not any(m in name for m in ('k_mmt<', 'k_mmt2<', 'k_mmt_bb<', 'k_mmq<', 'k_mmvq<')): continue
     v = float(r['Counter_Value']); n += 1; kib += v
     key = name.split('(')[0]; a = per.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += v
 res = {"hbm_bytes_per_launch": round(kib * 1024 * 2 / max(1, n)), "launches": n, "counter": "FETCH_SIZE (KiB) x 1024 x 2 (gfx950 correction)",
