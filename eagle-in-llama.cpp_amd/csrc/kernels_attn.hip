@@ -102,10 +102,12 @@ template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_at
     };
     if (wave*16 < n_kv) load_k(wave*16);
     f32x4 qr[NS][2];
+    const bool q16 = (((uintptr_t) a.q | (uintptr_t) a.q_nb1 | (uintptr_t) a.q_nb2) & 15) == 0;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const float * qp = (const float *)((const char *) a.q + (int64_t)(t0 + (col < nt ? col : 0)) * a.q_nb1 + (int64_t) h * a.q_nb2) + 32*s + 8*grp;
-        __builtin_memcpy(&qr[s][0], qp, 16); __builtin_memcpy(&qr[s][1], qp + 4, 16);      // rows are only known to be 4-byte aligned
+        if (q16) { qr[s][0] = *(const f32x4 *) qp; qr[s][1] = *(const f32x4 *)(qp + 4); }      // the usual case: two 16-byte loads
+        else { __builtin_memcpy(&qr[s][0], qp, 16); __builtin_memcpy(&qr[s][1], qp + 4, 16); }   // rows are only known to be 4-byte aligned
     }
     attn_stamp<STAMP>(1);                                  // everything requested
     f16x8 qf[NS];
@@ -140,6 +142,25 @@ template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_at
         if (t < nt) {
             float * row = sc + t*ldS;
             _Float16 * prow = ph + t*ldP;
+            constexpr int NR = 12;                              // scores per lane kept in registers: n_kv <= 12 lanes-per-token (384 cells at 32 lanes)
+            if (n_kv <= NR*lg) {
+                // one LDS read and one write per score instead of three round trips (max, exp, normalise passes over the LDS row): the
+                // phase is a latency chain at one wave per SIMD.  Same per-lane order of operations as the loop form below.
+                float v[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { const int i = sub + j*lg; v[j] = i < n_kv ? row[i] : -INFINITY; }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) mx = fmaxf(mx, v[j]);
+                mx = row_max_f(mx); if (lg == 32) mx = max_xw<16>(mx);
+                double sum = 0.0;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { if (sub + j*lg < n_kv) { const float e = (v[j] == -INFINITY) ? 0.0f : expf(v[j] - mx); v[j] = e; sum += (double) e; } }
+                sum = row_sum_d(sum); if (lg == 32) sum = sum_xw<16>(sum);
+                const float inv = (float)(1.0 / sum);
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { const int i = sub + j*lg; if (i < n_kv) prow[i] = (_Float16)(v[j] * inv); }
+            } else {
             float mx = -INFINITY;
             for (int i = sub; i < n_kv; i += lg) mx = fmaxf(mx, row[i]);
             mx = row_max_f(mx); if (lg == 32) mx = max_xw<16>(mx);            // 16 or 32 lanes per token: DPP row steps + one VALU lane-pair step
@@ -148,6 +169,7 @@ template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_at
             sum = row_sum_d(sum); if (lg == 32) sum = sum_xw<16>(sum);
             const float inv = (float)(1.0 / sum);
             for (int i = sub; i < n_kv; i += lg) prow[i] = (_Float16)(row[i] * inv);
+            }
         }
     }
     attn_stamp<STAMP>(4);

@@ -244,10 +244,28 @@ template <typename TS> __global__ void __launch_bounds__(256) k_get_rows(const c
     const TS v = *(const TS *)(tab + i0*dt.nb[0] + (int64_t) r*dt.nb[1] + i11*dt.nb[2] + i12*dt.nb[3]);
     *(float *)(d + i0*dd.nb[0] + i10*dd.nb[1] + i11*dd.nb[2] + i12*dd.nb[3]) = cvt<TS, float>(v);
 }
+// the hot shape (token embeddings of a verification batch / a chain step: a few rows of a contiguous f16 table): one block per output row,
+// 16 bytes of table per thread and step -- no per-element index arithmetic
+__global__ void __launch_bounds__(256) k_get_rows_f16_rows(const char * __restrict__ tab, const int32_t * __restrict__ idx, char * __restrict__ d, int64_t tab_nb1, int64_t d_nb1, int ne0) {
+    const int32_t r = idx[blockIdx.x];
+    const __half * src = (const __half *)(tab + (int64_t) r * tab_nb1);
+    float * out = (float *)(d + (int64_t) blockIdx.x * d_nb1);
+    for (int i = threadIdx.x * 8; i < ne0; i += 256 * 8) {
+        const float4 raw = *(const float4 *)(src + i);
+        const __half2 * h = (const __half2 *) &raw;
+        const float2 a = __half22float2(h[0]), b = __half22float2(h[1]), c = __half22float2(h[2]), e = __half22float2(h[3]);
+        *(float4 *)(out + i) = make_float4(a.x, a.y, b.x, b.y); *(float4 *)(out + i + 4) = make_float4(c.x, c.y, e.x, e.y);
+    }
+}
 void mi_op_get_rows(hipStream_t st, const ggml_tensor * dst) {
     const int64_t n = mi_nelements(dst);
     if (n == 0) return;
     const ggml_tensor * t = dst->src[0], * ix = dst->src[1];
+    if (t->type == GGML_TYPE_F16 && t->nb[0] == 2 && dst->nb[0] == 4 && (t->ne[0] % 8) == 0 && (t->nb[1] % 16) == 0 && (dst->nb[1] % 16) == 0 && (((uintptr_t) t->data | (uintptr_t) dst->data) & 15) == 0 &&
+        ix->type == GGML_TYPE_I32 && ix->nb[0] == 4 && ix->ne[1] == 1 && ix->ne[2] == 1 && ix->ne[3] == 1 && t->ne[2] == 1 && t->ne[3] == 1 && dst->ne[2] == 1 && dst->ne[3] == 1 && dst->ne[1] == ix->ne[0] && dst->ne[1] <= 65535) {
+        k_get_rows_f16_rows<<<(unsigned) dst->ne[1], 256, 0, st>>>((const char *) t->data, (const int32_t *) ix->data, (char *) dst->data, t->nb[1], dst->nb[1], (int) t->ne[0]);
+        return;
+    }
     const dim3 grid(cdiv(n, 256));
     if (t->type == GGML_TYPE_F32) k_get_rows<float><<<grid, 256, 0, st>>>((const char *) t->data, (const char *) ix->data, (char *) dst->data, mk_dims(t), mk_dims(ix), mk_dims(dst), n);
     else if (t->type == GGML_TYPE_F16) k_get_rows<__half><<<grid, 256, 0, st>>>((const char *) t->data, (const char *) ix->data, (char *) dst->data, mk_dims(t), mk_dims(ix), mk_dims(dst), n);
