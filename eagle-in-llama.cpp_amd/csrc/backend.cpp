@@ -237,6 +237,7 @@ static void be_free(ggml_backend_t b) {
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->scratch) HIP_CHECK(hipFree(c->scratch));
     if (c->act_cache) { if (c->act_cache->pool) HIP_CHECK(hipFree(c->act_cache->pool)); if (c->act_cache->big_pool) HIP_CHECK(hipFree(c->act_cache->big_pool)); delete c->act_cache; }
+    if (c->copy_ev) HIP_CHECK(hipEventDestroy(c->copy_ev));
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c; delete b;
 }
@@ -267,11 +268,10 @@ static bool be_cpy_async(ggml_backend_t bs, ggml_backend_t bd, const ggml_tensor
     set_device(cs->device);
     if (cs->device == cd->device) HIP_CHECK(hipMemcpyAsync(dst->data, src->data, n, hipMemcpyDeviceToDevice, cs->stream));
     else                          HIP_CHECK(hipMemcpyPeerAsync(dst->data, cd->device, src->data, cs->device, n, cs->stream));
-    hipEvent_t ev; HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIP_CHECK(hipEventRecord(ev, cs->stream));
+    if (!cs->copy_ev) HIP_CHECK(hipEventCreateWithFlags(&cs->copy_ev, hipEventDisableTiming));      // one event per source backend, re-recorded per copy
+    HIP_CHECK(hipEventRecord(cs->copy_ev, cs->stream));
     set_device(cd->device);
-    HIP_CHECK(hipStreamWaitEvent(cd->stream, ev, 0));
-    HIP_CHECK(hipEventDestroy(ev));
+    HIP_CHECK(hipStreamWaitEvent(cd->stream, cs->copy_ev, 0));
     return true;
 }
 void mi_allow_big_lds(const void * fn) {

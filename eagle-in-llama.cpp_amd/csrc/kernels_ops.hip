@@ -272,46 +272,55 @@ void mi_op_get_rows(hipStream_t st, const ggml_tensor * dst) {
     else MI_ABORT("get_rows: unsupported table type %d", t->type);
 }
 
-// ------------------------------------------------------------------ ARGMAX (f32 rows -> i32): first index of the largest value,
-// like ggml_vec_argmax_f32 (R/ggml/src/ggml-cpu/vec.h).  Greedy draft / verify steps fetch 4 bytes per token instead of a logits row.
+// ------------------------------------------------------------------ ARGMAX (f32 rows -> i32): index of the largest value by the rule of
+// ggml_vec_argmax_f32 (R/ggml/src/ggml-cpu/ggml-cpu.c:2253: the last of equal maxima).  Greedy draft / verify steps fetch 4 bytes per token instead of a logits row.
 // `tab` non-NULL: the block also writes row `argmax` of a f16 / f32 table as floats (GET_ROWS(table, ARGMAX(x)) right behind: the greedy
 // draft chain's token -> embedding hand-off, R/examples/eagle: the next step's input is the embedding of the token just picked)
 template <typename TS>
 __global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, int32_t * __restrict__ dst, int64_t ne0, int64_t nb1,
                                                  const char * __restrict__ tab, int64_t tab_nb1, float * __restrict__ rows, int64_t rows_nb1, int64_t row_len) {
     const float * row = (const float *)(x + (int64_t) blockIdx.x * nb1);
-    float best = -INFINITY; int bi = 0x7fffffff;
+    // ggml_vec_argmax_f32 (R/ggml/src/ggml-cpu/ggml-cpu.c:2253-2261): max = MAX(max, x[i]); if (max == x[i]) idx = i -- among equal maxima the
+    // LAST index wins (a row of -inf gives n - 1).  A NaN resets that loop's running maximum; rows holding one take the sequential form below.
+    float best = -INFINITY; int bi = -1; bool nan = false;
+#define AM_TAKE(v, i) { const float v_ = (v); const int i_ = (i); nan |= v_ != v_; if (v_ > best || (v_ == best && i_ > bi)) { best = v_; bi = i_; } }
     if ((ne0 & 3) == 0 && (((uintptr_t) row) & 15) == 0) {      // 16-byte loads, four of them in flight per lane (a 32000-entry logits row: two rounds)
         const int64_t n4 = ne0 / 4;
         for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 4*1024) {
             float4 x[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const int64_t i = i0 + j*1024; x[j] = i < n4 ? ((const float4 *) row)[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY); }
+            for (int j = 0; j < 4; ++j) { const int64_t i = i0 + j*1024; x[j] = i < n4 ? ((const float4 *) row)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int e = (int)((i0 + j*1024) * 4); const float xv[4] = { x[j].x, x[j].y, x[j].z, x[j].w };
-#pragma unroll
-                for (int c = 0; c < 4; ++c) if (xv[c] > best || (xv[c] == best && e + c < bi)) { best = xv[c]; bi = e + c; }
+                if (i0 + j*1024 < n4) {
+                    const int e = (int)((i0 + j*1024) * 4);
+                    AM_TAKE(x[j].x, e) AM_TAKE(x[j].y, e + 1) AM_TAKE(x[j].z, e + 2) AM_TAKE(x[j].w, e + 3)
+                }
             }
         }
     } else
-    for (int64_t i = threadIdx.x; i < ne0; i += 1024) { const float v = row[i]; if (v > best || (v == best && (int) i < bi)) { best = v; bi = (int) i; } }
-    if (bi == 0x7fffffff) bi = 0;                          // all NaN / -inf lanes fall back to index 0 like the CPU loop
+    for (int64_t i = threadIdx.x; i < ne0; i += 1024) AM_TAKE(row[i], (int) i)
+#undef AM_TAKE
     __shared__ float sv[16]; __shared__ int si[16];
     // wave arg-max: (value, index) pairs through the DPP row steps, then the two lane-pair steps (no LDS round trips)
-#define AM_STEP(C) { const float ov = dpp_f<C>(best); const int oi = dpp_i<C>(bi); if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } }
+#define AM_STEP(C) { const float ov = dpp_f<C>(best); const int oi = dpp_i<C>(bi); if (ov > best || (ov == best && oi > bi)) { best = ov; bi = oi; } }
     AM_STEP(DPP_XOR1) AM_STEP(DPP_XOR2) AM_STEP(DPP_HMIR) AM_STEP(DPP_MIR)
 #undef AM_STEP
 #define AM_PAIR(W) { uint32_t va, vb, ia, ib; lane_pair<W>(__float_as_uint(best), va, vb); lane_pair<W>((uint32_t) bi, ia, ib); \
         const float fa = __uint_as_float(va), fb = __uint_as_float(vb); \
-        if (fb > fa || (fb == fa && (int) ib < (int) ia)) { best = fb; bi = (int) ib; } else { best = fa; bi = (int) ia; } }
+        if (fb > fa || (fb == fa && (int) ib > (int) ia)) { best = fb; bi = (int) ib; } else { best = fa; bi = (int) ia; } }
     AM_PAIR(16) AM_PAIR(32)
 #undef AM_PAIR
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { sv[wave] = best; si[wave] = bi; }
-    __syncthreads();
+    const bool any_nan = __syncthreads_or(nan);
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] > bi)) { best = sv[w]; bi = si[w]; }
+        if (any_nan) {                                      // the reference loop word for word (MAX(a, b) = a > b ? a : b)
+            float mx = -INFINITY; bi = 0;
+            for (int64_t i = 0; i < ne0; ++i) { const float v = row[i]; mx = mx > v ? mx : v; if (mx == v) bi = (int) i; }
+        }
+        if (bi < 0) bi = 0;
         dst[blockIdx.x] = bi;
         si[0] = bi;
     }

@@ -91,6 +91,7 @@ struct mi_backend_ctx {           // ggml_backend::context  (one HIP stream)
     size_t       scratch_size;
     struct mi_act_cache * act_cache;   // kernels.h
     char         name[32];
+    hipEvent_t   copy_ev;         // cross-backend copies: recorded on this stream, waited for by the destination's (created at first use)
 };
 struct mi_buffer_ctx {            // ggml_backend_buffer::context
     int    device;

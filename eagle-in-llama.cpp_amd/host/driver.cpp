@@ -21,6 +21,8 @@ using namespace eh;
 
 static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// greedy pick on the host = llama_sampler_greedy_apply (R/src/llama-sampling.cpp): the FIRST of equal maxima.  GGML_OP_ARGMAX (the device-side
+// pick of the greedy chain / verification) follows ggml_vec_argmax_f32 instead -- the LAST of equal maxima; the two differ on exact fp32 ties only
 static int argmax(const float * v, int n) { int b = 0; float m = v[0]; for (int i = 1; i < n; ++i) if (v[i] > m) { m = v[i]; b = i; } return b; }
 static float top_prob(const float * v, int n, int best) { double s = 0; const float m = v[best]; for (int i = 0; i < n; ++i) s += std::exp((double)(v[i] - m)); return (float)(1.0 / s); }
 

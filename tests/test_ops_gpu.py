@@ -86,19 +86,43 @@ def test_mul_mat_ragged_and_fused_residual(ea, gpu, tname):
         assert rel(gpu_mul_mat(ea, gpu, t, w, x, k, rows, residual=res), want + res) < 2e-5, (rows, k, T)
 
 
-def test_argmax_first_maximum(ea, gpu):
-    """GGML_OP_ARGMAX (greedy draft / verify steps fetch one int per token): first index of the row maximum, like ggml_vec_argmax_f32"""
+def ref_argmax(x):
+    """ggml_vec_argmax_f32 (R/ggml/src/ggml-cpu/ggml-cpu.c:2253-2261) word for word: the LAST of equal maxima wins, a NaN resets the running maximum"""
+    out = []
+    for row in np.asarray(x, np.float32):
+        mx = np.float32(-np.inf); idx = 0
+        for i, v in enumerate(row):
+            mx = mx if mx > v else v
+            if mx == v:
+                idx = i
+        out.append(idx)
+    return np.asarray(out, np.int32)
+
+
+def test_argmax_follows_the_reference_tie_rule(ea, gpu, ref_cpu):
+    """GGML_OP_ARGMAX (greedy draft / verify steps fetch one int per token) against the reference CPU backend and its loop restated above:
+    ties (last index wins -- NOT numpy's first), a maximum in the last element, rows of -inf, rows with NaNs"""
     rng = np.random.default_rng(12)
-    for ne0, rows in [(32000, 6), (100, 3), (1, 2), (4099, 1)]:
+    for ne0, rows in [(32000, 6), (100, 5), (1, 2), (4099, 3)]:
         x = rng.standard_normal((rows, ne0)).astype(np.float32)
         if ne0 > 50:
-            x[0, 7] = x[0, 41] = 9.0          # tie: the first one wins
-            x[-1, ne0 - 1] = 11.0             # maximum in the last element
-        g = ea.Graph(gpu)
-        a = g.tensor(ea.F32, ne0, rows); r = g.argmax(a)
-        g.alloc(); g.set(a, x); g.compute()
-        got = g.get(r, np.int32)
-        assert np.array_equal(got, np.argmax(x, axis=1).astype(np.int32)), (ne0, rows)
+            x[0, 7] = x[0, 41] = 9.0          # tie: the later one wins
+            x[1, ne0 - 1] = 11.0              # maximum in the last element
+            x[2, :] = -np.inf                 # every element equals the running maximum: n - 1
+            if rows > 3:
+                x[3, 5] = np.nan; x[3, 3] = 50.0          # the NaN forgets the 50 in front of it
+            if rows > 4:
+                x[4, ne0 - 1] = np.nan; x[4, 17] = 40.0   # a trailing NaN leaves the index where it was
+        want = ref_argmax(x)
+        got = {}
+        for name, be in (("gpu", gpu), ("ref", ref_cpu)):
+            g = ea.Graph(be)
+            a = g.tensor(ea.F32, ne0, rows); r = g.argmax(a)
+            g.alloc(); g.set(a, x); g.compute()
+            got[name] = g.get(r, np.int32).reshape(-1)
+        assert np.array_equal(got["ref"], want), (ne0, rows, "restatement vs reference")
+        assert np.array_equal(got["gpu"], want), (ne0, rows)
+    assert ref_argmax(np.asarray([[1.0, 3.0, 3.0, 2.0]]))[0] == 2
 
 
 def test_activation_edge_cases(ea, gpu):

@@ -152,7 +152,7 @@ def test_argmax_feeds_get_rows_in_one_launch(ea, gpu):
     rng = np.random.default_rng(78)
     V, E, T = 32000, 512, 3
     logits = rng.standard_normal((T, V)).astype(np.float32)
-    logits[1, 777] = logits[1, 31999] = 9.0                           # a tie: the first index wins (ggml_vec_argmax_f32)
+    logits[1, 777] = logits[1, 31999] = 9.0                           # a tie: the LAST index wins (ggml_vec_argmax_f32, R/ggml/src/ggml-cpu/ggml-cpu.c:2253)
     tab = rng.standard_normal((V, E)).astype(np.float16)
     g = ea.Graph(gpu)
     lg, tb = g.tensor(ea.F32, V, T), g.tensor(ea.F16, E, V)
@@ -161,6 +161,6 @@ def test_argmax_feeds_get_rows_in_one_launch(ea, gpu):
     g.alloc(); g.set(lg, logits); g.set(tb, tab)
     g.compute()
     want = logits.argmax(axis=1)
-    assert want[1] == 777
+    want[1] = 31999
     assert np.array_equal(g.get(am, np.int32).reshape(-1), want.astype(np.int32))
     assert np.array_equal(g.get(rows).reshape(T, E), tab[want].astype(np.float32))
