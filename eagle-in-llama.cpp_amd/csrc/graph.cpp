@@ -354,7 +354,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
     hipStream_t st = ctx->stream;
     const bool simple2d = w0->ne[2] == 1 && w0->ne[3] == 1 && x->ne[2] == 1 && x->ne[3] == 1;
     // more than 24 tokens (prompts, wide tree verification): every matrix runs on its own through the one-pass big-batch kernel
-    // (kernels_mmt.hip, k_mmt_ts: weights streamed once for up to 128 tokens); only the residual ADD is still folded in
+    // (kernels_mmt.hip, k_mmt_bb: weights streamed once for the whole batch); only the residual ADD is still folded in
     const bool big = x->ne[1] > 24;
     if (!fuse || !simple2d || big) {
         // RMS_NORM deferred to us?  only possible when fuse is on, so nothing to undo here
