@@ -30,8 +30,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f16x8 as_h8(const i32x4 v) { return __builtin_bit_cast(f16x8, v); }
 __device__ __forceinline__ float rnd16(float v) { return __half2float(__float2half_rn(v)); }
 
-// LDS image: sc [tt][n_kv + 4] fp32 scores, ph [tt][n_kv + 8] f16 probabilities, red [4][64] float4 partial tiles
-static inline size_t attn_lds_bytes(int n_kv, int tt) { return (size_t) tt * (n_kv + 4) * 4 + (size_t) tt * (n_kv + 8) * 2 + 4 * 64 * 16 + 4 * 4 * 1024; }    // + per-wave V staging (row-major V only)
+// LDS image: sc [tt][n_kv + 4] fp32 scores -- the f16 probabilities of a token overwrite the front half of its own score row (probability i
+// lands on bytes of score i/2, which the same wave read in an earlier or the same step) --, red [4][64] float4 partial tiles.  32 bytes
+// per cell at 8 tokens: the fused kernel reaches n_kv = 4096 (Llama-2's context) inside 150 KiB; a separate probability image stopped at ~3000
+static inline size_t attn_lds_bytes(int n_kv, int tt) { return (size_t) tt * (n_kv + 4) * 4 + 4 * 64 * 16 + 4 * 4 * 1024; }    // + per-wave V staging (row-major V only)
 
 // diagnostic stamps (GGML_MI355X_ATTN_STAMPS, scripts/attn_stamps.py): the STAMP = true instantiation writes s_memrealtime at the phase
 // boundaries into a debug buffer nothing else reads; the product instantiation contains no stamp code
@@ -48,10 +50,10 @@ template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_at
     extern __shared__ __attribute__((aligned(16))) char lds[];
     attn_stamp<STAMP>(0);
     const int n_kv = a.n_kv;
-    const int ldS = n_kv + 4, ldP = n_kv + 8;
+    const int ldS = n_kv + 4, ldP = 2*ldS;                  // ldP: the same row pitch counted in f16 elements
     float    * sc  = (float *) lds;
-    _Float16 * ph  = (_Float16 *)(lds + (size_t) tt * ldS * 4);
-    f32x4    * red = (f32x4 *)(lds + (size_t) tt * ldS * 4 + (size_t) tt * ldP * 2);
+    _Float16 * ph  = (_Float16 *) lds;                     // probabilities in place (see attn_lds_bytes)
+    f32x4    * red = (f32x4 *)(lds + (size_t) tt * ldS * 4);
     _Float16 * stg = (_Float16 *)((char *) red + 4*64*16);              // [4 waves][4 chunks][32 cells][16 head dims]: row-major V -> B operands
     const int h = blockIdx.x, t0 = blockIdx.y * tt;
     const int nt = min(tt, a.T - t0);

@@ -263,3 +263,27 @@ def test_attention_subgraph_tree_mask(ea, gpu):
     p = g.get(sm).reshape(H, T, n_kv)
     assert rel(p, orc.soft_max(g.get(kqt).reshape(H, T, n_kv), mask, float(z["at_scale"]))) < 2e-6
     assert np.all(p[:, np.isinf(mask[:T])] == 0)   # masked cells get exactly zero probability
+
+
+@pytest.mark.parametrize("n_kv,T", [(4096, 6), (4096, 1), (2048, 13), (6144, 4)])
+def test_attention_long_context(ea, gpu, n_kv, T):
+    """The fused attention kernel keeps a token's scores and probabilities in ONE LDS row (probabilities in place): n_kv = 4096 at 8 tokens per block
+    (Llama-2's context) stays on it; 6144 cells fall back to the node-by-node path.  Both against the restatement."""
+    rng = np.random.default_rng(n_kv + T)
+    H, Hkv, d = 8, 4, 128
+    q = rng.standard_normal((T, H, d)).astype(np.float32)
+    kc = rng.standard_normal((Hkv, n_kv, d)).astype(np.float16)
+    vc = rng.standard_normal((Hkv, d, n_kv)).astype(np.float16)
+    mask = np.zeros((64, n_kv), np.float32)
+    for t in range(T):
+        mask[t, n_kv - 3 * (T - t):] = -np.inf           # a causal tail
+        mask[t, 100 + 7 * t: 140 + 7 * t] = -np.inf      # and a hole, different per token (tree-style)
+    scale = 1.0 / np.sqrt(d)
+    g = ea.Graph(gpu)
+    tq = g.tensor(ea.F32, d, H, T); tk = g.tensor(ea.F16, d, n_kv, Hkv); tv = g.tensor(ea.F16, n_kv, d, Hkv); tm = g.tensor(ea.F32, n_kv, 64)
+    kqt = g.mul_mat(tk, g.permute(tq, 0, 2, 1, 3))
+    sm = g.soft_max(kqt, tm, float(scale))
+    res = g.cont(g.permute(g.mul_mat(tv, sm), 0, 2, 1, 3))
+    g.alloc(); g.set(tq, q); g.set(tk, kc); g.set(tv, vc); g.set(tm, mask); g.compute()
+    got = g.get(res).reshape(T, H, d)
+    assert rel(got, orc.attention(q, kc, vc, mask, float(scale), Hkv)) < 1e-3
