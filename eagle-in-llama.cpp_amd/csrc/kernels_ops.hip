@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, in
     // ggml_vec_argmax_f32 (R/ggml/src/ggml-cpu/ggml-cpu.c:2253-2261): max = MAX(max, x[i]); if (max == x[i]) idx = i -- among equal maxima the
     // LAST index wins (a row of -inf gives n - 1).  A NaN resets that loop's running maximum; rows holding one take the sequential form below.
     float best = -INFINITY; int bi = -1; bool nan = false;
-#define AM_TAKE(v, i) { const float v_ = (v); const int i_ = (i); nan |= v_ != v_; if (v_ > best || (v_ == best && i_ > bi)) { best = v_; bi = i_; } }
+#define AM_TAKE(v, i) { const float v_ = (v); nan |= v_ != v_; if (v_ >= best) { best = v_; bi = (i); } }      // a thread walks its indices upwards: >= keeps the last of equals
     if ((ne0 & 3) == 0 && (((uintptr_t) row) & 15) == 0) {      // 16-byte loads, four of them in flight per lane (a 32000-entry logits row: two rounds)
         const int64_t n4 = ne0 / 4;
         for (int64_t i0 = threadIdx.x; i0 < n4; i0 += 4*1024) {
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, in
     } else
     for (int64_t i = threadIdx.x; i < ne0; i += 1024) AM_TAKE(row[i], (int) i)
 #undef AM_TAKE
-    __shared__ float sv[16]; __shared__ int si[16];
+    __shared__ float sv[16]; __shared__ int si[16]; __shared__ int sn[16];
     // wave arg-max: (value, index) pairs through the DPP row steps, then the two lane-pair steps (no LDS round trips)
 #define AM_STEP(C) { const float ov = dpp_f<C>(best); const int oi = dpp_i<C>(bi); if (ov > best || (ov == best && oi > bi)) { best = ov; bi = oi; } }
     AM_STEP(DPP_XOR1) AM_STEP(DPP_XOR2) AM_STEP(DPP_HMIR) AM_STEP(DPP_MIR)
@@ -312,9 +312,12 @@ __global__ void __launch_bounds__(1024) k_argmax(const char * __restrict__ x, in
     AM_PAIR(16) AM_PAIR(32)
 #undef AM_PAIR
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
-    const bool any_nan = __syncthreads_or(nan);
+    const bool wave_nan = __any(nan);
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; sn[wave] = wave_nan; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        bool any_nan = false;
+        for (int w = 0; w < 16; ++w) any_nan |= sn[w] != 0;
         for (int w = 1; w < 16; ++w) if (sv[w] > best || (sv[w] == best && si[w] > bi)) { best = sv[w]; bi = si[w]; }
         if (any_nan) {                                      // the reference loop word for word (MAX(a, b) = a > b ? a : b)
             float mx = -INFINITY; bi = 0;
