@@ -236,7 +236,7 @@ static void be_free(ggml_backend_t b) {
     set_device(c->device);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->scratch) HIP_CHECK(hipFree(c->scratch));
-    if (c->act_cache) { if (c->act_cache->pool) HIP_CHECK(hipFree(c->act_cache->pool)); if (c->act_cache->big_pool) HIP_CHECK(hipFree(c->act_cache->big_pool)); delete c->act_cache; }
+    if (c->act_cache) { if (c->act_cache->pool) HIP_CHECK(hipFree(c->act_cache->pool)); if (c->act_cache->big_pool) HIP_CHECK(hipFree(c->act_cache->big_pool)); if (c->act_cache->rope_tab) HIP_CHECK(hipFree(c->act_cache->rope_tab)); delete c->act_cache; }
     if (c->copy_ev) HIP_CHECK(hipEventDestroy(c->copy_ev));
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c; delete b;

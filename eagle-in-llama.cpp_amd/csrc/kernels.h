@@ -34,7 +34,10 @@ struct mmvq_mat {
     int relu;                           // EPI_F32: max(x, 0) after the residual / bias (fused GGML_UNARY_OP_RELU)
     const int32_t * ids; int n_ids;     // EPI_F32 in the tiled kernel, ids non-NULL: token t's result goes to output row j for every ids[j] == t (fused GET_ROWS(., inp_out_ids))
 };
-struct mmvq_rope { const int32_t * pos; int head_dim; float theta_scale, freq_scale, attn_factor; };
+struct mmvq_rope { const int32_t * pos; int head_dim; float theta_scale, freq_scale, attn_factor;
+                   const float * tab; };     // tab non-NULL (tiled kernel): {cos, sin} * attn_factor per (token, pair), built once per forward pass by mi_rope_table
+// {cos, sin} table of a RoPE (mode NORM) for T positions: [T][head_dim/2][2] floats, the arithmetic of the fused epilogue / ggml_rope_cache_init
+void mi_rope_table(hipStream_t st, const int32_t * pos, int T, int head_dim, float theta_scale, float freq_scale, float attn_factor, float * tab);
 struct mmvq_launch { act_src act; int k; int n_mat; int swiglu; mmvq_mat m[3]; mmvq_rope rope; int tiled; };   // tiled: every W is in the layout of tile_layout.h (kernels_mmt.hip)
 #define MI_ACT_SLOTS 8
 struct mi_act_cache {                  // quantised-activation images in HBM scratch (see mi_mmvq_run)
@@ -42,6 +45,8 @@ struct mi_act_cache {                  // quantised-activation images in HBM scr
     struct entry { const void * key; uint64_t epoch; int t0, T, kq, k; } e[MI_ACT_SLOTS] = {};
     // whole-batch images of the big-batch kernel (k_mmt_bb): 4 x 8 MiB, allocated at first use
     char * big_pool = nullptr; int big_next = 0; entry big[4] = {};
+    // RoPE table shared by the layers of one forward pass (graph.cpp): valid for `rope_epoch == epoch` and the key below
+    float * rope_tab = nullptr; uint64_t rope_epoch = 0; const void * rope_pos = nullptr; int rope_T = 0, rope_hd = 0; float rope_p[3] = {0, 0, 0};
 };
 int  mi_mmvq_max_tokens(int type, int k);
 size_t mi_act_image_bytes(int type, int T, int k);

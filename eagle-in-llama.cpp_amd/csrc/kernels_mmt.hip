@@ -439,11 +439,15 @@ __device__ __forceinline__ void mmt_body(const mmvq_launch & L, const int T, con
                 } else {   // RoPE (mode NORM) on the row pair (2p, 2p+1) = quads q, q^1 = lanes l, l^NW; theta by the reference's float recurrence (ggml_rope_cache_init)
                     const float pr = __shfl_xor(v0, NW);
                     if (act) {
-                        float th = (float) L.rope.pos[tok];
                         const int ip = (row % L.rope.head_dim) >> 1;
-                        for (int j = 0; j < ip; ++j) th *= L.rope.theta_scale;
-                        const float a = L.rope.freq_scale * th;
-                        const float c = cosf(a) * L.rope.attn_factor, sn = sinf(a) * L.rope.attn_factor;
+                        float c, sn;
+                        if (L.rope.tab) { const float2 cs = *(const float2 *)(L.rope.tab + ((size_t) tok * (L.rope.head_dim >> 1) + ip) * 2); c = cs.x; sn = cs.y; }     // same numbers, computed once per forward pass
+                        else {
+                            float th = (float) L.rope.pos[tok];
+                            for (int j = 0; j < ip; ++j) th *= L.rope.theta_scale;
+                            const float a = L.rope.freq_scale * th;
+                            c = cosf(a) * L.rope.attn_factor; sn = sinf(a) * L.rope.attn_factor;
+                        }
                         const float x0 = (row & 1) ? pr : v0, x1 = (row & 1) ? v0 : pr;
                         const float y = (row & 1) ? x0*sn + x1*c : x0*c - x1*sn;
                         if (M.epi == EPI_ROPE_F32) *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = y;
@@ -470,6 +474,21 @@ template <int TA, int TB, bool PFA, bool PFB>
 __global__ void __launch_bounds__(16*WAVE) k_mmt2(const mmvq_launch LA, const mmvq_launch LB, const int T, const int nbuf, const int gridA) {
     if ((int) blockIdx.x < gridA) mmt_body<TA, false, PFA, 1, 16, false>(LA, T, nbuf, 0, blockIdx.x, gridA);
     else                          mmt_body<TB, false, PFB, 1, 16, false>(LB, T, nbuf, 0, blockIdx.x - gridA, gridDim.x - gridA);
+}
+
+// theta of pair ip at position p by the reference's float recurrence (ggml_rope_cache_init: theta starts at p and is multiplied by theta_scale
+// per pair), then cos / sin scaled by attn_factor: exactly what the fused RoPE epilogue computes per element -- here once per (token, pair)
+__global__ void __launch_bounds__(128) k_rope_table(const int32_t * __restrict__ pos, float * __restrict__ tab, const int half, const float theta_scale, const float freq_scale, const float attn_factor) {
+    const int tok = blockIdx.x;
+    for (int ip = threadIdx.x; ip < half; ip += blockDim.x) {
+        float th = (float) pos[tok];
+        for (int j = 0; j < ip; ++j) th *= theta_scale;
+        const float a = freq_scale * th;
+        *(float2 *)(tab + ((size_t) tok * half + ip) * 2) = make_float2(cosf(a) * attn_factor, sinf(a) * attn_factor);
+    }
+}
+void mi_rope_table(hipStream_t st, const int32_t * pos, int T, int head_dim, float theta_scale, float freq_scale, float attn_factor, float * tab) {
+    k_rope_table<<<T, 128, 0, st>>>(pos, tab, head_dim / 2, theta_scale, freq_scale, attn_factor);
 }
 
 // ---------------------------------------------------------------- host side
@@ -830,6 +849,7 @@ void mi_mmt_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_a
         L.act.pre = nullptr;
         for (int i = 0; i < L.n_mat; ++i) { L.m[i].out += (size_t) t0 * L.m[i].o_tok; if (L.m[i].res) L.m[i].res += (size_t) t0 * L.m[i].r_tok; }
         if (L.rope.pos) L.rope.pos += t0;
+        if (L.rope.tab) L.rope.tab += (size_t) t0 * (L.rope.head_dim >> 1) * 2;
         if (!mmt_inline_quant(T, L)) {
             MI_ASSERT(mi_act_image_bytes(type, T, L.k) <= cache->slot_bytes);
             L.act.pre = mmt_image(st, type, T, t0, L, cache, key);
