@@ -463,7 +463,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
         L.rope.theta_scale = powf(mi_op_f32(rope0, 5), -2.0f / mi_op_i32(rope0, 1));
         L.rope.freq_scale = mi_op_f32(rope0, 6); L.rope.attn_factor = mi_op_f32(rope0, 8);
         L.rope.tab = nullptr;
-        // Every layer of a forward pass rotates by the same positions: when this graph holds at least eight ROPE nodes over these positions the
+        // Every layer of a forward pass rotates by the same positions: when this graph holds at least four ROPE nodes (two layers) over these positions the
         // {cos, sin} values are computed once (a 4 us launch) instead of in every epilogue of every layer (theta by a recurrence of up to 63
         // dependent multiplies, then sinf / cosf: ~4 us per q|k|v launch at 6 tokens).  A chain step's single layer keeps the in-epilogue form.
         static const bool tab_on = getenv("GGML_MI355X_NO_ROPE_TABLE") == nullptr;
@@ -474,7 +474,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
             if (!hit) {
                 int users = 0;
                 for (int j = 0; j < c.n; ++j) { const ggml_tensor * r = c.g->nodes[j]; if (r->op == GGML_OP_ROPE && r->src[1] == pos) users++; }
-                if (users >= 8) {
+                if (users >= 4) {
                     if (!ac->rope_tab) HIP_CHECK(hipMalloc((void **) &ac->rope_tab, (size_t) 24 * 128 * 2 * sizeof(float)));
                     mi_rope_table(st, L.rope.pos, T, L.rope.head_dim, L.rope.theta_scale, L.rope.freq_scale, L.rope.attn_factor, ac->rope_tab);
                     ac->rope_epoch = ac->epoch; ac->rope_pos = pos->data; ac->rope_T = T; ac->rope_hd = L.rope.head_dim;
