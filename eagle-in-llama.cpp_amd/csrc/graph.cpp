@@ -468,20 +468,26 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
         // dependent multiplies, then sinf / cosf: ~4 us per q|k|v launch at 6 tokens).  A chain step's single layer keeps the in-epilogue form.
         static const bool tab_on = getenv("GGML_MI355X_NO_ROPE_TABLE") == nullptr;
         mi_act_cache * ac = ctx->act_cache;
-        if (tab_on && tiled0 && T <= 24 && L.rope.head_dim <= 256 && (L.rope.head_dim % 2) == 0 && pos->type == GGML_TYPE_I32 && pos->ne[0] >= T) {
-            const bool hit = ac->rope_epoch == ac->epoch && ac->rope_pos == pos->data && ac->rope_T == T && ac->rope_hd == L.rope.head_dim &&
+        // positions may be a slice of a longer tensor (the draft chain keeps the positions of all its steps in one input and hands every step a
+        // view): the table covers the root, a launch reads its rows
+        const ggml_tensor * root = pos->view_src ? pos->view_src : pos;
+        const int64_t poff = ((const char *) pos->data - (const char *) root->data) / 4, Troot = root->ne[0];
+        if (tab_on && tiled0 && T <= 24 && Troot <= 24 && L.rope.head_dim <= 256 && (L.rope.head_dim % 2) == 0 && pos->type == GGML_TYPE_I32 && root->type == GGML_TYPE_I32 &&
+            root->nb[0] == 4 && mi_nrows(root) == 1 && poff >= 0 && poff + T <= Troot) {
+            const bool hit = ac->rope_epoch == ac->epoch && ac->rope_pos == root->data && ac->rope_T == (int) Troot && ac->rope_hd == L.rope.head_dim &&
                              ac->rope_p[0] == L.rope.theta_scale && ac->rope_p[1] == L.rope.freq_scale && ac->rope_p[2] == L.rope.attn_factor;
+            const float * rows = ac->rope_tab + (size_t) poff * (L.rope.head_dim / 2) * 2;
             if (!hit) {
                 int users = 0;
-                for (int j = 0; j < c.n; ++j) { const ggml_tensor * r = c.g->nodes[j]; if (r->op == GGML_OP_ROPE && r->src[1] == pos) users++; }
+                for (int j = 0; j < c.n; ++j) { const ggml_tensor * r = c.g->nodes[j]; if (r->op == GGML_OP_ROPE && r->src[1] && (r->src[1] == root || r->src[1]->view_src == root)) users++; }
                 if (users >= 4) {
-                    if (!ac->rope_tab) HIP_CHECK(hipMalloc((void **) &ac->rope_tab, (size_t) 24 * 128 * 2 * sizeof(float)));
-                    mi_rope_table(st, L.rope.pos, T, L.rope.head_dim, L.rope.theta_scale, L.rope.freq_scale, L.rope.attn_factor, ac->rope_tab);
-                    ac->rope_epoch = ac->epoch; ac->rope_pos = pos->data; ac->rope_T = T; ac->rope_hd = L.rope.head_dim;
+                    if (!ac->rope_tab) { HIP_CHECK(hipMalloc((void **) &ac->rope_tab, (size_t) 24 * 128 * 2 * sizeof(float))); rows = ac->rope_tab + (size_t) poff * (L.rope.head_dim / 2) * 2; }
+                    mi_rope_table(st, (const int32_t *) root->data, (int) Troot, L.rope.head_dim, L.rope.theta_scale, L.rope.freq_scale, L.rope.attn_factor, ac->rope_tab);
+                    ac->rope_epoch = ac->epoch; ac->rope_pos = root->data; ac->rope_T = (int) Troot; ac->rope_hd = L.rope.head_dim;
                     ac->rope_p[0] = L.rope.theta_scale; ac->rope_p[1] = L.rope.freq_scale; ac->rope_p[2] = L.rope.attn_factor;
-                    L.rope.tab = ac->rope_tab;
+                    L.rope.tab = rows;
                 }
-            } else L.rope.tab = ac->rope_tab;
+            } else L.rope.tab = rows;
         }
     }
     mmvq_launch LB = L; LB.act.norm_out = nullptr;                         // the second type's partition of a mixed-type launch

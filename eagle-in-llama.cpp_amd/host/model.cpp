@@ -641,11 +641,16 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
         in[j].T = T; in[j].Tpad = Tpad;
         in[j].embd = j == 0 && !dev_first ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_embd") : nullptr;
         in[j].hidd = j == 0 && !dev_first ? g.new_tensor(GGML_TYPE_F32, E, T, 1, 1, "inp_hidd") : nullptr;
-        in[j].pos  = g.new_tensor(GGML_TYPE_I32, T, 1, 1, 1, "inp_pos");
+        in[j].pos  = nullptr;                                                     // a view of pos_all, below
         in[j].mask = g.new_tensor(GGML_TYPE_F32, n_kv, Tpad, 1, 1, "KQ_mask");
         in[j].out  = g.new_tensor(GGML_TYPE_I32, 1, 1, 1, 1, "inp_out_ids");
         for (ggml_tensor * t : { in[j].embd, in[j].hidd, in[j].pos, in[j].mask, in[j].out }) if (t) { t->flags |= GGML_TENSOR_FLAG_INPUT; inputs.push_back(t); }
     }
+    // the positions of all steps in ONE input, every step rotating by its slice: the plugin then builds the RoPE table of the chain once
+    // instead of computing cos / sin in five q|k epilogues (csrc/graph.cpp)
+    ggml_tensor * pos_all = g.new_tensor(GGML_TYPE_I32, T0 + n_steps - 1, 1, 1, 1, "inp_pos");
+    pos_all->flags |= GGML_TENSOR_FLAG_INPUT; inputs.push_back(pos_all);
+    for (int j = 0; j < n_steps; ++j) in[j].pos = g.view_1d(pos_all, in[j].T, (size_t)(j == 0 ? 0 : T0 + j - 1) * 4);
     const bool saved_want = want_logits;
     want_logits = false;                                        // every step ends in GGML_OP_ARGMAX
     std::vector<ggml_tensor *> amax(n_steps);
@@ -686,6 +691,7 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
     auto host_of = [&](ggml_tensor * t) -> char * { if (packed) return stage_in + ((char *) t->data - (char *) base->data); unpacked.resize(mh::nbytes(t)); return unpacked.data(); };
     auto flush = [&](ggml_tensor * t, char * h) { if (!packed) g.set(t, h, 0, mh::nbytes(t)); };
     { char * h = host_of(chain_ids); memset(h, 0, mh::nbytes(chain_ids)); memcpy(h, &first.token[T0 - 1], 4); flush(chain_ids, h); }
+    std::vector<int32_t> pos_host((size_t) T0 + n_steps - 1);
     for (int j = 0; j < n_steps; ++j) {
         const Batch & b = bs[j]; const int T = in[j].T;
         if (in[j].embd) {
@@ -694,7 +700,7 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
             flush(in[j].embd, (char *) embd);
             char * h = host_of(in[j].hidd); memcpy(h, b.hidd.data(), (size_t) T * E * 4); flush(in[j].hidd, h);
         }
-        { char * h = host_of(in[j].pos); memcpy(h, b.pos.data(), (size_t) T * 4); flush(in[j].pos, h); }
+        memcpy(pos_host.data() + (j == 0 ? 0 : T0 + j - 1), b.pos.data(), (size_t) T * 4);
         { int32_t last = T - 1; char * h = host_of(in[j].out); memcpy(h, &last, 4); flush(in[j].out, h); }
         float * mask = (float *) host_of(in[j].mask);
         std::fill(mask, mask + (size_t) n_kv * T, -INFINITY);
@@ -705,6 +711,7 @@ int Model::decode_chain(const Batch & first, int n_steps, std::vector<int32_t> &
         }
         flush(in[j].mask, (char *) mask);
     }
+    { char * h = host_of(pos_all); memcpy(h, pos_host.data(), pos_host.size() * 4); flush(pos_all, h); }
     if (packed) g.set_async(base, stage_in, 0, span);
     const double t2 = now_us();
 
