@@ -345,4 +345,3 @@ template <int TG> struct mq_proc<GGML_TYPE_Q4_0, TG> { template <class F> static
         }
     }
 } };
-

@@ -12,7 +12,7 @@ objs = [os.path.join(PKG, "lib", "obj-plugin", n + ".hip.o") for n in ("kernels_
 out = os.path.join(PKG, "lib", "lab_mmx")
 obj = "/tmp/lab_mmx.o"
 flags = (["-DLAB_ALL_TYPES"] if "--all-types" in sys.argv else []) + (["-save-temps", "-Rpass-analysis=kernel-resource-usage"] if "--temps" in sys.argv else [])
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{PKG}/csrc", "--offload-arch=gfx950", "-Wno-unused-result", "-x", "hip", "-c",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{PKG}/csrc", f"-I{ROOT}/scripts", "--offload-arch=gfx950", "-Wno-unused-result", "-x", "hip", "-c",
        os.path.join(ROOT, "scripts", "lab_mmx.hip"), "-o", obj] + flags
 print(" ".join(cmd)); subprocess.check_call(cmd, cwd="/tmp")
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", obj] + objs + ["-o", out]

@@ -57,33 +57,38 @@ __global__ void k_rewrite(float * x, const float * src, int n, float eps) {     
 
 struct variant { std::string name; int pfd; int flags; bool old; };
 
-template <int TYPE, bool DUAL> static void launch_mmx(hipStream_t st, const mmvq_launch & L, int T, int want_depth, int flags, unsigned long long * stamps, bool stamp) {
+template <int TYPE, bool DUAL, bool HOIST> static void launch_mmx(hipStream_t st, const mmvq_launch & L, int T, int want_depth, int flags, unsigned long long * stamps, bool stamp, const mx_next & nx) {
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int TILE = mq_tfrag<TYPE>::TILE;
-    int nbuf = MX_F_NBUF(flags);
-    if (nbuf >= 2 && mx_ring_depth(T, L.k, DUAL, Q80, 2, TILE, 2) < 2) { nbuf = 1; flags = (flags & ~3) | 1; }
-    const int depth = mx_ring_depth(T, L.k, DUAL, Q80, nbuf, TILE, want_depth);
+    int nbuf = MX_F_NBUF(flags), batch = MX_F_BATCH(flags);
+    static unsigned epoch = 0; flags |= (int)((++epoch & 0xfffu) << 20);
+    while (batch > 1 && mx_ring_depth(T, L.k, DUAL, Q80, nbuf, TILE, 2, batch) < 2) { if (nbuf > 1) nbuf = 1; else --batch; }
+    if (nbuf >= 2 && mx_ring_depth(T, L.k, DUAL, Q80, 2, TILE, 2, batch) < 2) nbuf = 1;
+    flags = (flags & ~(3 | (7 << 16))) | nbuf | (batch << 16);
+    const int depth = mx_ring_depth(T, L.k, DUAL, Q80, nbuf, TILE, want_depth, batch);
     if (depth < 1) { fprintf(stderr, "no LDS for a tile ring\n"); exit(1); }
     flags |= depth << 12;
-    const size_t lds = mx_lds_bytes(T, L.k, DUAL, Q80, nbuf) + (size_t) 16 * depth * TILE;
+    const size_t lds = mx_lds_bytes(T, L.k, DUAL, Q80, nbuf, batch) + (size_t) 16 * depth * TILE;
     int total = 0;
     if (DUAL) total = L.m[0].rows / 16; else for (int i = 0; i < L.n_mat; ++i) total += L.m[i].rows / 16;
     const int grid = total < 256 ? total : 256;
-    auto fn = k_mmx<TYPE, DUAL, true>;      // the lab runs the stamp instantiation only (stamps == nullptr: a scalar branch per stamp point)
+    auto fn = k_mmx<TYPE, DUAL, HOIST, true>;      // the lab runs the stamp instantiation only (stamps == nullptr: a scalar branch per stamp point)
     static bool once = false; if (!once) { mi_allow_big_lds((const void *) fn); once = true; }
-    fn<<<grid, 1024, lds, st>>>(L, T, flags, stamp ? stamps : nullptr);
+    fn<<<grid, 1024, lds, st>>>(L, T, flags, stamp ? stamps : nullptr, (flags & 0x400) ? nx : mx_next{ nullptr, 0, 0 });
 }
-template <int TYPE> static void launch_type(hipStream_t st, const mmvq_launch & L, int T, int pfd, int flags, unsigned long long * stamps, bool stamp) {
-    if (L.swiglu) launch_mmx<TYPE, true>(st, L, T, pfd, flags, stamps, stamp); else launch_mmx<TYPE, false>(st, L, T, pfd, flags, stamps, stamp);
+template <int TYPE> static void launch_type(hipStream_t st, const mmvq_launch & L, int T, int pfd, int flags, unsigned long long * stamps, bool stamp, const mx_next & nx) {
+    const bool hoist = (flags & 0x200) && L.k <= 4096 && mq_aop<TYPE>::HAVE;
+    if (L.swiglu) { if (hoist) launch_mmx<TYPE, true, true>(st, L, T, pfd, flags, stamps, stamp, nx); else launch_mmx<TYPE, true, false>(st, L, T, pfd, flags, stamps, stamp, nx); }
+    else          { if (hoist) launch_mmx<TYPE, false, true>(st, L, T, pfd, flags, stamps, stamp, nx); else launch_mmx<TYPE, false, false>(st, L, T, pfd, flags, stamps, stamp, nx); }
 }
-static void launch_any(hipStream_t st, int type, const mmvq_launch & L, int T, int pfd, int flags, unsigned long long * stamps, bool stamp) {
+static void launch_any(hipStream_t st, int type, const mmvq_launch & L, int T, int pfd, int flags, unsigned long long * stamps, bool stamp, const mx_next & nx) {
     switch (type) {
-        case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, L, T, pfd, flags, stamps, stamp); break;
-        case GGML_TYPE_Q6_K: launch_type<GGML_TYPE_Q6_K>(st, L, T, pfd, flags, stamps, stamp); break;
+        case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, L, T, pfd, flags, stamps, stamp, nx); break;
+        case GGML_TYPE_Q6_K: launch_type<GGML_TYPE_Q6_K>(st, L, T, pfd, flags, stamps, stamp, nx); break;
 #ifdef LAB_ALL_TYPES
-        case GGML_TYPE_Q5_K: launch_type<GGML_TYPE_Q5_K>(st, L, T, pfd, flags, stamps, stamp); break;
-        case GGML_TYPE_Q8_0: launch_type<GGML_TYPE_Q8_0>(st, L, T, pfd, flags, stamps, stamp); break;
-        case GGML_TYPE_Q4_0: launch_type<GGML_TYPE_Q4_0>(st, L, T, pfd, flags, stamps, stamp); break;
+        case GGML_TYPE_Q5_K: launch_type<GGML_TYPE_Q5_K>(st, L, T, pfd, flags, stamps, stamp, nx); break;
+        case GGML_TYPE_Q8_0: launch_type<GGML_TYPE_Q8_0>(st, L, T, pfd, flags, stamps, stamp, nx); break;
+        case GGML_TYPE_Q4_0: launch_type<GGML_TYPE_Q4_0>(st, L, T, pfd, flags, stamps, stamp, nx); break;
 #endif
         default: fprintf(stderr, "lab built without this type\n"); exit(1);
     }
@@ -140,12 +145,16 @@ int main(int argc, char ** argv) {
 
     std::vector<variant> vars;
     vars.push_back({ "r2 k_mmt", 0, 0, true });
-    auto add = [&](int d, int pf) { vars.push_back({ "mmx d" + std::to_string(d) + " pf" + std::to_string(pf), d, 2 | (pf << 4), false }); };
-    add(1, 2); add(2, 2); add(3, 2); add(4, 2); add(2, 1); add(4, 1);
+    auto add = [&](int d, int pf, int hoist, int batch, int nxt) { vars.push_back({ "mmx d" + std::to_string(d) + " pf" + std::to_string(pf) + (hoist ? " hoist" : "") + " g" + std::to_string(batch) + (nxt ? " next" : ""), d, 2 | (pf << 4) | (hoist << 9) | (batch << 16) | (nxt << 10), false }); };
+    add(2, 2, 1, 1, 0); add(2, 2, 1, 1, 1); add(4, 2, 1, 2, 0); add(4, 2, 1, 2, 1); add(4, 2, 1, 4, 1);
     auto run_one = [&](const variant & v, int r, float * out, bool stamp) {
         mmvq_launch L = make(r, out);
         if (v.old) mi_mmt_run(st, type, T, L, &cache, nullptr);
-        else launch_any(st, type, L, T, v.pfd, v.flags, stamps, stamp);
+        else {
+            // the next launch of the timed sequence streams repetition r + 1's first matrix: its row groups in tile order
+            const mx_next nx = { W[(size_t)((r + 1) % nrep) * nmat], (int)(rb * 16), rows / 16 };
+            launch_any(st, type, L, T, v.pfd, v.flags, stamps, stamp, nx);
+        }
     };
     // ---- correctness: bit for bit against the round-2 kernel
     std::vector<float> ref(obytes / 4), got(obytes / 4), nref((size_t) T*k), ngot((size_t) T*k);

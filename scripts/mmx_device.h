@@ -20,18 +20,123 @@
 #include "mmq_device.h"
 #include "tile_layout.h"
 
-#define MX_RLD 65                       // f32x4 slots per wave in a reduction buffer (64 lanes + 1: spreads the readers over the banks)
+#define MX_RLD 33                       // f32x4 slots per wave in a reduction buffer (32 lanes + 1: spreads the readers over the banks)
 #define MX_NSTAMP 12
-#define MX_QSCRATCH 17408                // the quantiser's LDS scratch: 1 KiB of partial sums + 16 KiB of norm weights (its own region: a wave may
+#define MX_QSCRATCH 17424                // the quantiser's LDS scratch: 1 KiB of partial sums + 16 KiB of norm weights (its own region: a wave may
                                         // still be quantising when another one parks its first partial tile)
 
 typedef float mxf4 __attribute__((ext_vector_type(4)));
+
+// ---- the activation operands of ONE unit held in registers: a wave that multiplies the same unit of every row group (k <= 4096: one unit per
+// wave and group) reads them from the LDS image once instead of once per row group, and the per-group predication of those reads goes too.
+// mq_run_pre repeats mq_proc::run on them operation for operation (same results bit for bit).
+template <int TYPE> struct mq_aop { static constexpr bool HAVE = false; };
+template <int TYPE> struct mq_aop45 {
+    static constexpr bool HAVE = true;
+    i32x4 a[2][2], am; float dy[4];
+    __device__ __forceinline__ void load(const mq_act & A, int sb, int lane) {
+        const int i = lane & 15, kq = lane >> 4, tok_a = i & 7, cls_a = i >> 3;
+        const bool av = cls_a == (kq >> 1) && tok_a < A.T;
+        const int8_t * arow = A.q + tok_a*A.ldq + sb*256 + 128*cls_a + 16*(kq & 1);
+#pragma unroll
+        for (int ga = 0; ga < 2; ++ga) { a[ga][0] = av ? *(const i32x4 *)(arow + 64*ga) : (i32x4)(0); a[ga][1] = av ? *(const i32x4 *)(arow + 64*ga + 32) : (i32x4)(0); }
+        am = (kq == 0 && tok_a < A.T) ? *(const i32x4 *)(A.rec + (tok_a*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int tok = 4*(kq & 1) + r; dy[r] = tok < A.T ? A.d[tok*A.nsb + sb] : 0.f; }
+    }
+};
+template <> struct mq_aop<GGML_TYPE_Q4_K> : mq_aop45<GGML_TYPE_Q4_K> {};
+template <> struct mq_aop<GGML_TYPE_Q5_K> : mq_aop45<GGML_TYPE_Q5_K> {};
+template <> struct mq_aop<GGML_TYPE_Q6_K> {
+    static constexpr bool HAVE = true;
+    i32x4 a[2][2], am; float dy[4];          // a[nn][nib]: the operand of this lane's own pass (p == qb); the other pass multiplies zeros
+    __device__ __forceinline__ void load(const mq_act & A, int sb, int lane) {
+        const int i = lane & 15, kq = lane >> 4, qb = kq >> 1, lh = kq & 1, tok_a = i & 7, cls_a = i >> 3;
+        const bool av = cls_a == lh && tok_a < A.T;
+        const int8_t * arow = A.q + tok_a*A.ldq + sb*256 + 16*lh;
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int nib = 0; nib < 2; ++nib) a[nn][nib] = av ? *(const i32x4 *)(arow + 128*nn + 32*(qb + 2*nib)) : (i32x4)(0);
+        am = (kq == 0 && tok_a < A.T) ? *(const i32x4 *)(A.rec + (tok_a*A.nsb + sb)*32 + 16*cls_a) : (i32x4)(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int tok = 4*(kq & 1) + r; dy[r] = tok < A.T ? A.d[tok*A.nsb + sb] : 0.f; }
+    }
+};
+template <int TYPE, class F> __device__ __forceinline__ void mq_run_pre(const F & f, const mq_aop<TYPE> & P, int lane, float (&acc)[1][4]) {
+    const int kq = lane >> 4, g = kq;
+    if constexpr (TYPE == GGML_TYPE_Q4_K || TYPE == GGML_TYPE_Q5_K) {
+        const uint32_t u0 = f.hdr.y, u1 = f.hdr.z, u2 = f.hdr.w;
+        const uint32_t s_lo = u0 & 0x3f3f3f3fu, s_hi = (u2 & 0x0f0f0f0fu) | ((u0 >> 2) & 0x30303030u);
+        const uint32_t m_lo = u1 & 0x3f3f3f3fu, m_hi = ((u2 >> 4) & 0x0f0f0f0fu) | ((u1 >> 2) & 0x30303030u);
+        const float dw = h2f((uint16_t)(f.hdr.x & 0xffff)), mw = h2f((uint16_t)((uint32_t) f.hdr.x >> 16));
+        const uint32_t sw = (g >> 1) ? s_hi : s_lo;
+        int isum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int ga = 0; ga < 2; ++ga) {
+            i32x4 blo = f.qs[ga] & 0x0F0F0F0F, bhi = (f.qs[ga] >> 4) & 0x0F0F0F0F;
+            if constexpr (TYPE == GGML_TYPE_Q5_K) {
+                const i32x4 hb = (kq >> 1) ? (f.qh >> 4) : f.qh;
+                blo |= ((hb >> (2*ga)) & 0x01010101) << 4; bhi |= ((hb >> (2*ga + 1)) & 0x01010101) << 4;
+            }
+            const int s0 = byte_of(sw, 2*ga), s1 = byte_of(sw, 2*ga + 1);
+            const i32x4 c0 = mfma_i8(P.a[ga][0], blo);
+            const i32x4 c1 = mfma_i8(P.a[ga][1], bhi);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) isum[r] += __mul24(s0, c0[r]) + __mul24(s1, c1[r]);
+        }
+        i32x4 bm = {0, 0, 0, 0};
+        if (kq == 0) { bm.x = (int) m_lo; bm.y = (int) m_hi; }
+        const float mscale = (g >> 1) ? 128.f : 1.f;
+        const i32x4 cm = mfma_i8(P.am, bm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][r] += (dw*P.dy[r])*(float) isum[r] - ((mw*P.dy[r])*mscale)*(float) cm[r];
+    } else {
+        static_assert(TYPE == GGML_TYPE_Q6_K, "mq_run_pre: K-quants only");
+        const int qb = kq >> 1, lh = kq & 1, cls = g >> 1;
+        int isum[4] = { 0, 0, 0, 0 };
+        const i32x4 qh_own = f.get_qh(), scv = f.get_sc();
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+            const int src = 4*((lane & 15) + 16*(2*nn + lh));
+            i32x4 qhn;
+            qhn.x = __builtin_amdgcn_ds_bpermute(src, qh_own.x); qhn.y = __builtin_amdgcn_ds_bpermute(src, qh_own.y);
+            qhn.z = __builtin_amdgcn_ds_bpermute(src, qh_own.z); qhn.w = __builtin_amdgcn_ds_bpermute(src, qh_own.w);
+            const i32x4 hq = qhn >> (2*qb);
+            const i32x4 qln = f.get_ql(nn);
+#pragma unroll
+            for (int nib = 0; nib < 2; ++nib) {
+                const i32x4 b = nib ? (((qln >> 4) & 0x0F0F0F0F) | (hq & 0x30303030)) : ((qln & 0x0F0F0F0F) | ((hq << 4) & 0x30303030));
+                const uint32_t sw = (uint32_t) scv[2*nn + nib] >> (8*cls);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int sc = sbyte_of(sw, 2*p);
+                    const i32x4 a = qb == p ? P.a[nn][nib] : (i32x4)(0);
+                    const i32x4 c = mfma_i8(a, b);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) isum[r] += __mul24(sc, c[r]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const i32x4 bm = kq == 0 ? scv : (i32x4)(0);
+        const float dw = h2f((uint16_t) f.dh);
+        const int mscale = (g >> 1) ? 128*32 : 32;
+        const i32x4 cm = mfma_i8(P.am, bm);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[0][r] += (dw*P.dy[r])*(float)(isum[r] - mscale*cm[r]);
+    }
+}
+
 
 // launch flags (low to high): bits 0-1 reduction buffers (1 | 2), bits 4-5 pfpos: where the prologue requests the first weight tiles (0 right
 // behind the activation loads | 1 once this wave's activations have landed | 2 once the norm scale is known / the image share is written)
 #define MX_F_NBUF(f)  ((f) & 3)
 #define MX_F_PFPOS(f) (((f) >> 4) & 3)
 #define MX_F_DEPTH(f) (((f) >> 12) & 7)        // bits 12-14: ring slots per wave (tiles in flight), 1..4
+#define MX_F_BATCH(f) (((f) >> 16) & 7)        // bits 16-18: row groups reduced behind one barrier, 1..MX_GMAX
+#define MX_F_EPOCH(f) (((unsigned)(f) >> 20) & 0xfffu)   // bits 20-31: launch epoch (mx_landing_rank)
+#define MX_GMAX 4
 
 template <bool STAMP> __device__ __forceinline__ void mx_stamp(unsigned long long * base, int idx, int lane) {
     if constexpr (STAMP) { if (lane == 0 && base) base[idx] = __builtin_amdgcn_s_memrealtime(); }
@@ -191,6 +296,23 @@ template <int TYPE, int LG> struct mx_q {
     }
 };
 
+// Order in which the waves of a block pass a point, without a barrier and without initialised LDS: the word holds (launch epoch << 8 | count);
+// the first wave of a launch finds another epoch and restarts the count.  The rank only steers WHEN a wave requests its tiles -- a stale word that
+// happens to carry this launch's 12-bit epoch costs time, never correctness.
+__device__ __forceinline__ int mx_landing_rank(unsigned * word, unsigned epoch, int lane) {
+    int rank = 0;
+    if (lane == 0) {
+        unsigned old = *(volatile unsigned *) word;
+        for (;;) {
+            const bool mine = (old >> 8) == epoch;
+            const unsigned want = mine ? old + 1 : ((epoch << 8) | 1u);
+            const unsigned seen = atomicCAS(word, old, want);
+            if (seen == old) { rank = mine ? (int)(old & 0xffu) : 0; break; }
+            old = seen;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(rank);
+}
 // `prefetch` issues the block's first weight-tile loads; pfpos says where (MX_F_PFPOS)
 template <int TYPE, int LG, int NSB, bool STAMP, class PFN>
 __device__ __forceinline__ void mx_norm_quant(const act_src & a, const int T, const int k, const int nun, const int nsb, const int ldq,
@@ -234,7 +356,7 @@ __device__ __forceinline__ void mx_norm_quant(const act_src & a, const int T, co
     const float mean = (k & (k - 1)) == 0 ? (float) __builtin_ldexp(tot, -__builtin_ctz(k)) : (float)(tot / (double) k);
     const float s1 = 1.0f / sqrtf(mean + a.eps);
     mx_stamp<STAMP>(stp, 10, lane);
-    if (pfpos >= 2) prefetch();
+    if (pfpos >= 2) prefetch();              // (3 = adaptive in the plain path; behind the norm barrier every wave's activations have landed)
 #pragma unroll
     for (int c = 0; c < NSB; ++c) {
         const int sb = wave + 16*c;
@@ -256,7 +378,7 @@ __device__ __forceinline__ void mx_norm_quant(const act_src & a, const int T, co
 template <int TYPE, int LG, bool STAMP, class PFN>
 __device__ __forceinline__ void mx_quantise_lg(const act_src & a, const int T, const int k, const int nun, const int nsb, const int ldq,
                                                int8_t * lq, float * ldy, char * lrec, double * rd, const int lane, const int wave, PFN prefetch, const int pfpos,
-                                               unsigned long long * stp) {
+                                               const unsigned epoch, unsigned long long * stp) {
     using Q = mx_q<TYPE, LG>;
     constexpr int NF = Q::NF;
     const int t = lane / LG, p = lane % LG;
@@ -271,21 +393,30 @@ __device__ __forceinline__ void mx_quantise_lg(const act_src & a, const int T, c
         if constexpr (STAMP) { if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); mx_stamp<STAMP>(stp, 7, lane); } }
         if (pfpos == 0) prefetch();
         if (pfpos == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); prefetch(); }
+        bool late = false;
+        if (pfpos == 3) {
+            // The block waits for its slowest wave at the first reduction, and that wave's chain is landing -> quantiser -> tile round trip ->
+            // products.  A wave whose activations land among the last eight of the block requests its tiles at once (the others' activation
+            // loads are done: nothing of theirs queues behind the requests any more); an early wave has the slack to ask after its quantiser
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            late = mx_landing_rank((unsigned *)((char *) rd + 17408), epoch, lane) >= 8;
+            if (late) prefetch();
+        }
         for (int sb = wave; sb < nun; sb += 16) {
             if (sb != wave) Q::load(a, x, tv, t, p, sb);
             Q::quant(x, tv, t, p, lane, T, sb, ldq, nsb, lq, ldy, lrec);
         }
-        if (pfpos >= 2) prefetch();
+        if (pfpos == 2 || (pfpos == 3 && !late)) prefetch();
     }
 }
 template <int TYPE, bool STAMP, class PFN>
 __device__ __forceinline__ void mx_quantise(const act_src & a, const int T, const int k, const int nun, const int nsb, const int ldq,
                                             int8_t * lq, float * ldy, char * lrec, double * rd, const int lane, const int wave, PFN prefetch, const int pfpos,
-                                            unsigned long long * stp) {
-    if (T == 1)      mx_quantise_lg<TYPE, 64, STAMP>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
-    else if (T == 2) mx_quantise_lg<TYPE, 32, STAMP>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
-    else if (T <= 4) mx_quantise_lg<TYPE, 16, STAMP>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
-    else             mx_quantise_lg<TYPE, 8, STAMP>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, stp);
+                                            const unsigned epoch, unsigned long long * stp) {
+    if (T == 1)      mx_quantise_lg<TYPE, 64, STAMP>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, epoch, stp);
+    else if (T == 2) mx_quantise_lg<TYPE, 32, STAMP>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, epoch, stp);
+    else if (T <= 4) mx_quantise_lg<TYPE, 16, STAMP>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, epoch, stp);
+    else             mx_quantise_lg<TYPE, 8, STAMP>(a, T, k, nun, nsb, ldq, lq, ldy, lrec, rd, lane, wave, prefetch, pfpos, epoch, stp);
 }
 
 // {cos, sin} of one rotation without the per-forward table (graphs with fewer than four ROPE nodes): theta by the reference's float recurrence
@@ -299,13 +430,13 @@ static inline size_t mx_img_bytes(int T, int k, bool q80) {
     const size_t nsc = q80 ? k/32 : k/256;
     return (size_t) T*(k + 16) + (((size_t) T*nsc*4 + 15) & ~(size_t) 15) + (q80 ? 0 : (size_t) T*nsc*32);
 }
-static inline size_t mx_lds_bytes(int T, int k, bool dual, bool q80, int nbuf) {
-    const size_t red = (size_t) nbuf * (dual ? 2 : 1) * 16 * MX_RLD * 16;
+static inline size_t mx_lds_bytes(int T, int k, bool dual, bool q80, int nbuf, int batch = 1) {
+    const size_t red = (size_t) nbuf * batch * (dual ? 2 : 1) * 16 * MX_RLD * 16;
     return mx_img_bytes(T, k, q80) + MX_QSCRATCH + red;                // image | quantiser scratch | reduction buffers (| tile ring: mx_ring_depth)
 }
 // ring slots per wave that fit behind the rest (at most `want`, at least 1; 0 = does not fit at all)
-static inline int mx_ring_depth(int T, int k, bool dual, bool q80, int nbuf, int tile, int want) {
-    const size_t base = mx_lds_bytes(T, k, dual, q80, nbuf);
+static inline int mx_ring_depth(int T, int k, bool dual, bool q80, int nbuf, int tile, int want, int batch = 1) {
+    const size_t base = mx_lds_bytes(T, k, dual, q80, nbuf, batch);
     if (base + (size_t) 16 * tile > 160*1024) return 0;
     int d = (int)((160*1024 - base) / ((size_t) 16 * tile));
     return d < want ? d : want;
@@ -317,11 +448,17 @@ static inline int mx_ring_depth(int T, int k, bool dual, bool q80, int nbuf, int
 // newest request to land first).  The statements are inline asm: hipcc does not count them, its own waits stay correct (vmcnt retires in
 // order; they can only over-wait), and the waits here are counted from the tiles requested behind the one that is needed.
 // LDS destination = M0 + lane * 16 (wave-uniform base, lane-linear): a slot holds the tile byte for byte as HBM does.
-__device__ __forceinline__ void mx_dma16(const char * gsrc, uint32_t lds_dst) {      // all active lanes: 16 bytes from gsrc to lds_dst + 16 lane
+template <bool NT = true> __device__ __forceinline__ void mx_dma16(const char * gsrc, uint32_t lds_dst) {      // all active lanes: 16 bytes from gsrc to lds_dst + 16 lane
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    if constexpr (NT) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// What the NEXT mat-vec launch of the graph will stream first (its row groups in tile order): a block whose own stream is exhausted keeps its
+// ring busy with those bytes -- default cache policy, never read from LDS -- so that they wait in L2 / the Infinity Cache when the next
+// launch asks for them 3 us into its prologue, instead of costing it an HBM round trip under a chip-wide burst.
+struct mx_next { const char * w; int group_bytes; int groups; };
 template <int TILE> __device__ __forceinline__ void mx_dma_tile(const char * tile, uint32_t slot, int lane) {
     constexpr int FULL = TILE / 1024, REST = (TILE % 1024) / 16;
     static_assert(TILE % 16 == 0, "tiles are whole 16-byte pieces");
@@ -355,8 +492,8 @@ template <int KOFF> __device__ __forceinline__ mx_matp mx_mat(int i) {
 // requested a group's tiles only when the previous group's units were done, i.e. one exposed HBM round trip per group (three per q|k|v
 // launch at k = 4096, where a wave has a single unit per group).
 // DUAL: gate | up with the SwiGLU epilogue; a group's stream elements alternate gate, up.
-template <int TYPE, bool DUAL, bool STAMP, int KOFF>
-__device__ __forceinline__ void mmx_body(const mmvq_launch & L, const int T, const int flags, const int bid, const int nblk, unsigned long long * stamp_base) {
+template <int TYPE, bool DUAL, bool HOIST, bool STAMP, int KOFF>
+__device__ __forceinline__ void mmx_body(const mmvq_launch & L, const int T, const int flags, const int bid, const int nblk, unsigned long long * stamp_base, const mx_next nx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 16;
     const int nbuf = MX_F_NBUF(flags), pfpos = MX_F_PFPOS(flags);
@@ -370,7 +507,7 @@ __device__ __forceinline__ void mmx_body(const mmvq_launch & L, const int T, con
     double * qscr = (double *)(lrec + (Q80 ? 0 : (size_t) T*nsb*32));
     f32x4  * red = (f32x4 *)((char *) qscr + MX_QSCRATCH);
     const int D = MX_F_DEPTH(flags);
-    char   * ring = (char *) red + (size_t) nbuf * NM * NW * MX_RLD * 16;          // [wave][slot][TILE]
+    char   * ring = (char *) red + (size_t) nbuf * MX_F_BATCH(flags) * NM * NW * MX_RLD * 16;          // [wave][slot][TILE]
     // the wave index through readfirstlane: everything derived from it (stream cursors, row groups, matrix index) is provably wave-uniform and
     // lives in scalar registers -- with a divergent-looking index into L.m[] the compiler copies the whole kernel argument to scratch
     const int tid = threadIdx.x, lane = tid % WAVE, wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
@@ -401,11 +538,26 @@ __device__ __forceinline__ void mmx_body(const mmvq_launch & L, const int T, con
         rslot = rslot + 1 == D ? 0 : rslot + 1; ++issued;
         if (++lu == nu) { lu = 0; lgrp += nblk; if (lgrp < total) lrows(); }
     };
+    // phantom requests (mx_next): 1 KiB chunks w, w + 16, ... of row group blockIdx.x of the next launch, as many as fit the slot just freed
+    int ph_ops = 0, ph_chunk = wave;
+    const int ph_n = (nx.w && (int) blockIdx.x < nx.groups) ? (nx.group_bytes + 1023) >> 10 : 0;
+    const char * const ph_base = nx.w + (size_t) blockIdx.x * nx.group_bytes;
+    auto phantom_into = [&](int slot) {
+#pragma unroll
+        for (int c = 0; c < TILE / 1024; ++c) {
+            if (ph_chunk < ph_n) {
+                const int left = nx.group_bytes - ph_chunk*1024;        // a group is whole 16-byte pieces
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane*16 < left) mx_dma16<false>(ph_base + (size_t) ph_chunk*1024 + lane*16, __builtin_amdgcn_readfirstlane(ring_lds + slot*TILE + c*1024));
+                ph_chunk += NW; ++ph_ops;
+            }
+        }
+    };
     auto prefetch = [&]() {          // the first D tiles of the stream are in flight across the prologue
         for (int j = 0; j < D; ++j) if (nu > 0 && lgrp < total) request_next();
     };
 
-    mx_quantise<TYPE, STAMP>(L.act, T, k, nun, nsb, ldq, lq, ldy, lrec, qscr, lane, wave, prefetch, pfpos, stp);
+    mx_quantise<TYPE, STAMP>(L.act, T, k, nun, nsb, ldq, lq, ldy, lrec, qscr, lane, wave, prefetch, pfpos, MX_F_EPOCH(flags), stp);
     mx_stamp<STAMP>(stp, 1, lane);                                 // this wave's share of the activation image is in LDS
     // No block barrier here: wave w multiplies exactly the super-blocks w, w + 16, ... it has just quantised itself (the units of its split-K
     // share), for every row group -- the image is wave-private; LDS is in order per wave
@@ -419,97 +571,126 @@ __device__ __forceinline__ void mmx_body(const mmvq_launch & L, const int T, con
     for (int m = 0; m < NM; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[m][0][r] = 0.f;
-    // split-K reduction + epilogue of row group bid + cgi nblk (every wave of the block calls it once per group, in the same order)
-    auto finish_group = [&]() {
-        const int grp = bid + cgi*nblk;
-        if (first) mx_stamp<STAMP>(stp, 3, lane);                 // first group's units done (weights arrived + MFMA work)
-        int cmi, crow0; rows_of(grp, cmi, crow0);
-        // ---- split-K reduction: every wave parks its partial tile, then 16 lanes per output quad (row n, tokens 4h..4h+3) add the
-        // 16 waves x 2 classes in a fixed order and the quad's first four lanes finish one token each
-        {
-            f32x4 * rb = red + (size_t) par * NM * NW * MX_RLD;
-            if (nbuf < 2) __syncthreads();                       // single buffer: the readers of the previous tile must be done
+    // ---- split-K reduction + epilogues, G row groups behind ONE barrier.
+    // park(j): a wave adds its two classes (lanes l, l ^ 32) and parks 32 x f32x4 -- partial sums of (row n = l & 15, tokens 4 (l >> 4) .. + 3) of
+    // the batch's j-th group -- right behind that group's units, and goes on with the next group's tiles.  reduce_batch(): behind the barrier all
+    // 16 waves reduce: a DPP row of 16 lanes holds the 16 waves' partials of (row n, token pair 4h + 2pr ..) of one group, four rows per wave,
+    // and the row's first two lanes finish one token each -- round 2 synchronised after every group and left the sums to waves 0..7, which
+    // then ran late into the next group.  What an epilogue needs from memory (residual, RoPE table) is requested before the barrier.
+    const int G = MX_F_BATCH(flags);
+    auto park = [&](int j) {
+        f32x4 * rb = red + (size_t)(par*G + j) * NM * NW * MX_RLD;
 #pragma unroll
-            for (int m = 0; m < NM; ++m) { const f32x4 v = { acc[m][0][0], acc[m][0][1], acc[m][0][2], acc[m][0][3] }; rb[(m*NW + wave)*MX_RLD + lane] = v; }
-            __syncthreads();
-            if (first) mx_stamp<STAMP>(stp, 4, lane);
-            if (tid < 32*NW) {
-                const int w = tid % NW, q = tid / NW, n = q & 15, h = q >> 4;
-                float s[NM][4];
+        for (int m = 0; m < NM; ++m) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = sum_xw<32>(acc[m][0][r]); acc[m][0][r] = 0.f; }
+            if (lane < 32) rb[(m*NW + wave)*MX_RLD + lane] = v;
+        }
+    };
+    auto reduce_batch = [&](int nb) {          // the batch's groups are bid + (cgi + j) nblk, j < nb
+        if (first) mx_stamp<STAMP>(stp, 3, lane);
+        const int qg = wave*4 + (lane >> 4), w = lane & 15;
+        const int n = qg & 15, h = (qg >> 4) & 1, pr = qg >> 5;
+        const int tok = 4*h + 2*pr + (w & 1);
+        const bool act = w < 2 && tok < T;
+        int row[MX_GMAX], cmi[MX_GMAX]; float resv[MX_GMAX]; float2 cs[MX_GMAX];
+#pragma unroll
+        for (int j = 0; j < MX_GMAX; ++j) {
+            resv[j] = 0.f; cs[j] = make_float2(1.f, 0.f); row[j] = 0; cmi[j] = 0;
+            if (j < nb) {
+                int crow0; rows_of(bid + (cgi + j)*nblk, cmi[j], crow0); row[j] = crow0 + n;
+                if (!DUAL && act) {
+                    const mx_matp M = mx_mat<KOFF>(cmi[j]);
+                    const int epi = M->epi;
+                    if (epi == EPI_F32) { if (M->res) resv[j] = M->res[(size_t) tok*M->r_tok + row[j]]; }
+                    else if (epi != EPI_F16) {     // RoPE (mode NORM): theta by the reference's float recurrence (ggml_rope_cache_init), from the per-forward table when there is one
+                        const int ip = (row[j] % L.rope.head_dim) >> 1;
+                        if (L.rope.tab) cs[j] = *(const float2 *)(L.rope.tab + ((size_t) tok * (L.rope.head_dim >> 1) + ip) * 2);
+                        else cs[j] = mx_rope_cs((float) L.rope.pos[tok], ip, L.rope.theta_scale, L.rope.freq_scale, L.rope.attn_factor);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (first) mx_stamp<STAMP>(stp, 4, lane);
+#pragma unroll
+        for (int j = 0; j < MX_GMAX; ++j) {
+            if (j < nb) {
+                const f32x4 * rb = red + (size_t)(par*G + j) * NM * NW * MX_RLD;
+                float s[NM][2];
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
-                    const f32x4 x = rb[(m*NW + w)*MX_RLD + q] + rb[(m*NW + w)*MX_RLD + q + 32];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s[m][r] = row_sum_f(x[r]);
+                    const float2 x = *(const float2 *)((const float *)(rb + (m*NW + w)*MX_RLD + n + 16*h) + 2*pr);
+                    s[m][0] = row_sum_f(x.x); s[m][1] = row_sum_f(x.y);
                 }
-                const mx_matp M = mx_mat<KOFF>(cmi);
-                const int row = crow0 + n, tok = 4*h + (w & 3);
-                const bool act = w < 4 && tok < T;
-                float v0 = (w & 3) == 0 ? s[0][0] : (w & 3) == 1 ? s[0][1] : (w & 3) == 2 ? s[0][2] : s[0][3];
+                const mx_matp M = mx_mat<KOFF>(cmi[j]);
+                const int epi = DUAL ? EPI_F32 : M->epi;
+                const float v0 = (w & 1) ? s[0][1] : s[0][0];
+                char * const optr = M->out + (size_t) row[j]*M->o_row;
                 if (DUAL) {
-                    const float v1 = (w & 3) == 0 ? s[NM-1][0] : (w & 3) == 1 ? s[NM-1][1] : (w & 3) == 2 ? s[NM-1][2] : s[NM-1][3];
-                    if (act) *(float *)(M->out + (size_t) row*M->o_row + (size_t) tok*M->o_tok) = (v0 / (1.0f + expf(-v0))) * v1;
-                } else if (M->epi == EPI_F32) {
+                    const float v1 = (w & 1) ? s[NM-1][1] : s[NM-1][0];
+                    if (act) *(float *)(optr + (size_t) tok*M->o_tok) = (v0 / (1.0f + expf(-v0))) * v1;
+                } else if (epi == EPI_F32) {
                     if (act) {
-                        float o = v0; if (M->res) o += M->res[(size_t) tok*M->r_tok + row]; if (M->relu) o = o > 0.f ? o : 0.f;
-                        if (!M->ids) *(float *)(M->out + (size_t) row*M->o_row + (size_t) tok*M->o_tok) = o;
-                        else for (int j = 0; j < M->n_ids; ++j) if (M->ids[j] == tok) *(float *)(M->out + (size_t) row*M->o_row + (size_t) j*M->o_tok) = o;      // output rows that select this token
+                        float o = M->res ? v0 + resv[j] : v0; if (M->relu) o = o > 0.f ? o : 0.f;
+                        if (!M->ids) *(float *)(optr + (size_t) tok*M->o_tok) = o;
+                        else for (int i = 0; i < M->n_ids; ++i) if (M->ids[i] == tok) *(float *)(optr + (size_t) i*M->o_tok) = o;      // output rows that select this token
                     }
-                } else if (M->epi == EPI_F16) {
-                    if (act) *(__half *)(M->out + (size_t) row*M->o_row + (size_t) tok*M->o_tok) = __float2half_rn(v0);
-                } else {   // RoPE (mode NORM) on the row pair (2p, 2p+1) = quads q, q^1 = lanes l, l^NW; theta by the reference's float recurrence (ggml_rope_cache_init)
-                    const float pr = __shfl_xor(v0, NW);
+                } else if (epi == EPI_F16) {
+                    if (act) *(__half *)(optr + (size_t) tok*M->o_tok) = __float2half_rn(v0);
+                } else {   // RoPE on the row pair (2p, 2p+1) = neighbouring DPP rows = lanes l, l ^ 16
+                    const float prt = __shfl_xor(v0, 16);
                     if (act) {
-                        const int ip = (row % L.rope.head_dim) >> 1;
-                        float c, sn;
-                        if (L.rope.tab) { const float2 cs = *(const float2 *)(L.rope.tab + ((size_t) tok * (L.rope.head_dim >> 1) + ip) * 2); c = cs.x; sn = cs.y; }
-                        else { const float2 cs = mx_rope_cs((float) L.rope.pos[tok], ip, L.rope.theta_scale, L.rope.freq_scale, L.rope.attn_factor); c = cs.x; sn = cs.y; }
-                        const float x0 = (row & 1) ? pr : v0, x1 = (row & 1) ? v0 : pr;
-                        const float y = (row & 1) ? x0*sn + x1*c : x0*c - x1*sn;
-                        if (M->epi == EPI_ROPE_F32) *(float *)(M->out + (size_t) row*M->o_row + (size_t) tok*M->o_tok) = y;
-                        else                       *(__half *)(M->out + (size_t) row*M->o_row + (size_t) tok*M->o_tok) = __float2half_rn(y);
+                        const float x0 = (row[j] & 1) ? prt : v0, x1 = (row[j] & 1) ? v0 : prt;
+                        const float y = (row[j] & 1) ? x0*cs[j].y + x1*cs[j].x : x0*cs[j].x - x1*cs[j].y;
+                        if (epi == EPI_ROPE_F32) *(float *)(optr + (size_t) tok*M->o_tok) = y;
+                        else                     *(__half *)(optr + (size_t) tok*M->o_tok) = __float2half_rn(y);
                     }
                 }
             }
-            if (nbuf >= 2) par ^= 1;
         }
+        if (nbuf >= 2) par ^= 1; else __syncthreads();          // single buffer: the next batch parks into the slots just read
         if (first) mx_stamp<STAMP>(stp, 5, lane);
-        first = false; ++cgi;
-#pragma unroll
-        for (int m = 0; m < NM; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[m][0][r] = 0.f;
+        first = false; cgi += nb;
     };
     const int ngr = bid < total ? (total - bid + nblk - 1) / nblk : 0;
-    if (nu == 0) {                    // a wave without units (k < 4096) still takes part in every reduction
-        for (int g = 0; g < ngr; ++g) finish_group();
-    } else {
-        int cslot = 0;
-        for (int g = 0; g < ngr; ++g) {
-            for (int cu = 0; cu < nu; ++cu) {
+    mq_aop<TYPE> P;                 // HOIST: this wave's single unit of activations (k <= 4096), read from the image once
+    if constexpr (HOIST) { if (nu > 0) P.load(A, wave, lane); }
+    int cslot = 0;
+    for (int g0 = 0; g0 < ngr; g0 += G) {
+        const int nb = ngr - g0 < G ? ngr - g0 : G;
+        for (int j = 0; j < nb; ++j) {
+            for (int cu = 0; cu < nu; ++cu) {         // (a wave without units, k < 4096, parks zeros)
                 const int unit = DUAL ? wave + (cu >> 1)*NW : wave + cu*NW;
-                mx_wait_vm((issued - consumed - 1) * mx_dma_ops<TILE>());          // the tiles requested behind this one may stay in flight
+                mx_wait_vm((issued - consumed - 1) * mx_dma_ops<TILE>() + ph_ops);   // what was requested behind this tile may stay in flight
                 mq_tfrag<TYPE> f;
                 f.template load<false>(myring + (size_t) cslot * TILE, lane, 0);
-                if (DUAL && (cu & 1)) mq_proc<TYPE, 1>::run(f, A, unit, lane, acc[NM - 1]);
-                else                  mq_proc<TYPE, 1>::run(f, A, unit, lane, acc[0]);
-                ++consumed; cslot = cslot + 1 == D ? 0 : cslot + 1;
-                if (lgrp < total) request_next();                                  // into the slot just read (ring order = stream order)
+                if constexpr (HOIST) {
+                    if (DUAL && (cu & 1)) mq_run_pre<TYPE>(f, P, lane, acc[NM - 1]); else mq_run_pre<TYPE>(f, P, lane, acc[0]);
+                } else {
+                    if (DUAL && (cu & 1)) mq_proc<TYPE, 1>::run(f, A, unit, lane, acc[NM - 1]); else mq_proc<TYPE, 1>::run(f, A, unit, lane, acc[0]);
+                }
+                ++consumed;
+                if (lgrp < total) request_next(); else phantom_into(cslot);        // into the slot just read (ring order = stream order)
+                cslot = cslot + 1 == D ? 0 : cslot + 1;
             }
-            finish_group();
+            park(j);
         }
+        reduce_batch(nb);
     }
     mx_stamp<STAMP>(stp, 6, lane);
 }
 
-template <int TYPE, bool DUAL, bool STAMP = false>
-__global__ void __launch_bounds__(16*WAVE) k_mmx(const mmvq_launch L, const int T, const int flags, unsigned long long * stamps) {
-    mmx_body<TYPE, DUAL, STAMP, 0>(L, T, flags, blockIdx.x, gridDim.x, stamps);
+// HOIST (k <= 4096 and a K-quant): the activation operands of a wave's single unit stay in registers across the row groups
+template <int TYPE, bool DUAL, bool HOIST, bool STAMP = false>
+__global__ void __launch_bounds__(16*WAVE) k_mmx(const mmvq_launch L, const int T, const int flags, unsigned long long * stamps, const mx_next nx) {
+    mmx_body<TYPE, DUAL, HOIST, STAMP, 0>(L, T, flags, blockIdx.x, gridDim.x, stamps, nx);
 }
 // Two launches that read the same activations but hold weights of different types (Q4_K_M: wq | wk are Q4_K, wv is Q6_K in half of the
 // layers) as ONE grid: blocks [0, gridA) run launch A's body, the rest launch B's
-template <int TA, int TB>
-__global__ void __launch_bounds__(16*WAVE) k_mmx2(const mmvq_launch LA, const mmvq_launch LB, const int T, const int flagsA, const int flagsB, const int gridA) {
-    if ((int) blockIdx.x < gridA) mmx_body<TA, false, false, 0>(LA, T, flagsA, blockIdx.x, gridA, nullptr);
-    else                          mmx_body<TB, false, false, (int) sizeof(mmvq_launch)>(LB, T, flagsB, blockIdx.x - gridA, gridDim.x - gridA, nullptr);
+template <int TA, int TB, bool HOIST>
+__global__ void __launch_bounds__(16*WAVE) k_mmx2(const mmvq_launch LA, const mmvq_launch LB, const int T, const int flagsA, const int flagsB, const int gridA, const mx_next nx) {
+    if ((int) blockIdx.x < gridA) mmx_body<TA, false, HOIST, false, 0>(LA, T, flagsA, blockIdx.x, gridA, nullptr, nx);
+    else                          mmx_body<TB, false, HOIST, false, (int) sizeof(mmvq_launch)>(LB, T, flagsB, blockIdx.x - gridA, gridDim.x - gridA, nullptr, nx);
 }
