@@ -71,6 +71,7 @@ def host():
             "eh_argmax": (vp, [vp, vp]),
             "eh_rope": (vp, [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, f32]),
             "eh_soft_max": (vp, [vp, vp, vp, f32, f32]),
+            "eh_top_k": (i32, [vp, vp, C.POINTER(C.c_int32), i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
             "eh_alloc": (i32, [vp]), "eh_compute": (i32, [vp]),
             "eh_set": (None, [vp, vp, vp, i64, i64]), "eh_get": (None, [vp, vp, vp, i64, i64]),
             "eh_supports": (i32, [vp, vp]), "eh_nbytes": (i64, [vp]), "eh_shape": (None, [vp, C.POINTER(i64), C.POINTER(i64)]),
@@ -197,6 +198,16 @@ class Graph:
 
     def soft_max(self, a, mask, scale=1.0, max_bias=0.0):
         return host().eh_soft_max(self.h, a, mask, scale, max_bias)
+
+    def top_k(self, a, k, rows=None):
+        """The backend's device-side top-k extension on an allocated, computed f32 tensor [n, n_rows]: (ids, values), each [len(rows)][k],
+        descending, ties by lower index; None when the backend offers no such extension (reference CPU backend)."""
+        ne = (C.c_int64 * 4)(); nb = (C.c_int64 * 4)(); host().eh_shape(a, ne, nb)
+        rows = list(range(ne[1])) if rows is None else list(rows)
+        r = (C.c_int32 * len(rows))(*rows)
+        ids = np.empty((len(rows), k), np.int32); vals = np.empty((len(rows), k), np.float32)
+        rc = host().eh_top_k(self.h, a, r, len(rows), k, ids.ctypes.data_as(C.POINTER(C.c_int32)), vals.ctypes.data_as(C.POINTER(C.c_float)))
+        return (ids, vals) if rc == 0 else None
 
     def alloc(self):
         if host().eh_alloc(self.h) != 0:

@@ -381,8 +381,37 @@ extern "C" ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int 
 
 // extension for hosts that interleave their own stream work (RCCL collectives between graph segments)
 static void * backend_stream(ggml_backend_t b) { return be_is_ours(b) ? (void *) ((mi_backend_ctx *) b->context)->stream : nullptr; }
+// extension for hosts that draft trees: the k best logits of a few rows without bringing the rows to the host (include/ggml_mi355x.h)
+extern "C" GGML_MI355X_API int ggml_backend_mi355x_top_k(ggml_backend_t b, const ggml_tensor * logits, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals) {
+    if (!be_is_ours(b) || !logits || !logits->buffer || !mi_buffer_is_ours(logits->buffer) || !logits->data || n_rows < 0 || !mi_top_k_supported(logits, k)) return -1;
+    if (n_rows == 0) return 0;
+    mi_backend_ctx * c = (mi_backend_ctx *) b->context; set_device(c->device);
+    for (int i = 0; i < n_rows; ++i) if ((rows ? rows[i] : i) < 0 || (rows ? rows[i] : i) >= logits->ne[1]) return -1;
+    // results: [n_rows][k] ids | [n_rows][k] values in a small device buffer and its page-locked twin, kept with the backend instance
+    static std::mutex mu; struct stage { mi_backend_ctx * ctx; char * dev; char * host; size_t cap; }; static std::vector<stage> stages;
+    const size_t need = (size_t) n_rows * k * 8;
+    stage * s = nullptr;
+    { std::lock_guard<std::mutex> lk(mu); for (auto & e : stages) if (e.ctx == c) s = &e; if (!s) { stages.push_back({ c, nullptr, nullptr, 0 }); s = &stages.back(); }
+      if (s->cap < need) {
+          HIP_CHECK(hipStreamSynchronize(c->stream));
+          if (s->dev) HIP_CHECK(hipFree(s->dev)); if (s->host) HIP_CHECK(hipHostFree(s->host));
+          s->cap = need < 16384 ? 16384 : need * 2;
+          HIP_CHECK(hipMalloc((void **) &s->dev, s->cap)); HIP_CHECK(hipHostMalloc((void **) &s->host, s->cap, hipHostMallocDefault));
+      } }
+    int32_t * d_ids = (int32_t *) s->dev; float * d_vals = (float *)(s->dev + (size_t) n_rows * k * 4);
+    for (int r0 = 0; r0 < n_rows; r0 += 16) {
+        const int n = n_rows - r0 < 16 ? n_rows - r0 : 16;
+        int32_t rr[16]; for (int i = 0; i < n; ++i) rr[i] = rows ? rows[r0 + i] : r0 + i;
+        mi_top_k(c->stream, logits, rr, n, k, d_ids + (size_t) r0 * k, d_vals + (size_t) r0 * k);
+    }
+    HIP_CHECK(hipMemcpyAsync(s->host, s->dev, need, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(ids, s->host, (size_t) n_rows * k * 4); memcpy(vals, s->host + (size_t) n_rows * k * 4, (size_t) n_rows * k * 4);
+    return 0;
+}
 static void * reg_proc(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_stream"))     return (void *) backend_stream;
+    if (!strcmp(name, "ggml_backend_mi355x_top_k"))      return (void *) ggml_backend_mi355x_top_k;
     if (!strcmp(name, "ggml_backend_get_features"))      return (void *) reg_get_features;
     if (!strcmp(name, "ggml_backend_split_buffer_type")) return (void *) ggml_backend_mi355x_split_buffer_type;
     return nullptr;

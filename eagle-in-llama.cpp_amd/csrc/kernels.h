@@ -16,6 +16,9 @@ void mi_op_argmax   (hipStream_t st, const ggml_tensor * dst, const ggml_tensor 
 bool mi_argmax_rows_supported(const ggml_tensor * dst, const ggml_tensor * rows);
 void mi_op_rope     (hipStream_t st, const ggml_tensor * dst);
 void mi_op_soft_max (hipStream_t st, const ggml_tensor * dst);
+// k largest entries of n_rows <= 16 rows of an f32 matrix, descending, ties: lower index first; ids / vals are device arrays [n_rows][k]
+bool mi_top_k_supported(const ggml_tensor * logits, int k);
+void mi_top_k(hipStream_t st, const ggml_tensor * logits, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals);
 // fused SwiGLU tail: dst = silu(gate) * up   (UNARY(SILU) followed by MUL)
 void mi_op_silu_mul (hipStream_t st, const ggml_tensor * gate, const ggml_tensor * up, const ggml_tensor * dst);
 

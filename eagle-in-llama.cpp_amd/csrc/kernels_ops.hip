@@ -352,6 +352,70 @@ void mi_op_argmax(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * r
     else                            k_argmax<float><<<(unsigned) n, 1024, 0, st>>>((const char *) a->data, (int32_t *) dst->data, a->ne[0], a->nb[1], (const char *) tab->data, tab->nb[1], (float *) rows->data, rows->nb[1], tab->ne[0]);
 }
 
+// ------------------------------------------------------------------ top-k of logits rows on the device (second half)
+// Tree drafting takes the k best candidates of every live branch at every depth (R/common/speculative.cpp:257-272: the sampler's sorted
+// cur_p; R/examples/speculative/speculative-eagle.cpp:542-625 forks on cur_p[f].p).  Round 2 brought a whole logits row (128 KB) per branch
+// to the host and partial_sorted 32 000 entries there: 11.6 ms of a config-3 round.  Here one block per row selects the k largest in
+// descending order -- ties: the LOWER index first (the order of the host's `better`, tree_driver.cpp) -- and 8 k bytes per row come back.
+// A thread keeps its elements i = tid + 1024 j in registers; every round the block takes the maximum of the 64-bit keys
+// (ordered value bits << 32 | ~index) and only the winner's owner looks for its next best.
+__device__ __forceinline__ uint32_t topk_ord(float v) { const uint32_t b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }      // monotone float -> uint
+__device__ __forceinline__ float    topk_val(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+struct topk_rows { int32_t r[16]; };
+template <int J>
+__global__ void __launch_bounds__(1024) k_topk(const char * __restrict__ x, int64_t ne0, int64_t nb1, topk_rows rows, int k, int32_t * __restrict__ ids, float * __restrict__ vals) {
+    const float * row = (const float *)(x + (int64_t) rows.r[blockIdx.x] * nb1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { const int64_t i = tid + 1024*(int64_t) j; v[j] = i < ne0 ? row[i] : 0.f; }
+    unsigned long long alive = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) if (tid + 1024*(int64_t) j < ne0) alive |= 1ull << j;
+    __shared__ unsigned long long wk[2][16];
+    auto local_best = [&]() -> unsigned long long {
+        unsigned long long best = 0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const unsigned long long key = ((unsigned long long) topk_ord(v[j]) << 32) | (0xffffffffu - (uint32_t)(tid + 1024*j));
+            if (((alive >> j) & 1) && key > best) best = key;
+        }
+        return best;
+    };
+    unsigned long long mine = local_best();
+    for (int it = 0; it < k; ++it) {
+        unsigned long long m = mine;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint32_t lo = (uint32_t) __shfl_xor((int)(uint32_t) m, off), hi = (uint32_t) __shfl_xor((int)(uint32_t)(m >> 32), off);
+            const unsigned long long o = ((unsigned long long) hi << 32) | lo;
+            m = o > m ? o : m;
+        }
+        if (lane == 0) wk[it & 1][wave] = m;
+        __syncthreads();                                        // (double-buffered: one barrier per round)
+        unsigned long long w = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const unsigned long long o = wk[it & 1][i]; w = o > w ? o : w; }
+        if (w == 0) {                                           // fewer than k elements in the row
+            if (tid == 0) { ids[(int64_t) blockIdx.x * k + it] = -1; vals[(int64_t) blockIdx.x * k + it] = -INFINITY; }
+            continue;
+        }
+        const uint32_t idx = 0xffffffffu - (uint32_t) w;
+        if (tid == 0) { ids[(int64_t) blockIdx.x * k + it] = (int32_t) idx; vals[(int64_t) blockIdx.x * k + it] = topk_val((uint32_t)(w >> 32)); }
+        if ((int)(idx & 1023) == tid) { alive &= ~(1ull << (idx >> 10)); mine = local_best(); }
+    }
+}
+// ids / vals: DEVICE arrays [n_rows][k]; rows: host array of n_rows <= 16 row indices of `logits` (f32, contiguous rows)
+bool mi_top_k_supported(const ggml_tensor * logits, int k) {
+    return logits && logits->type == GGML_TYPE_F32 && logits->nb[0] == 4 && logits->ne[0] >= 1 && logits->ne[0] <= 64*1024 && k >= 1 && k <= 64 && logits->ne[2] == 1 && logits->ne[3] == 1;
+}
+void mi_top_k(hipStream_t st, const ggml_tensor * logits, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals) {
+    MI_ASSERT(n_rows >= 1 && n_rows <= 16 && mi_top_k_supported(logits, k));
+    topk_rows r{}; for (int i = 0; i < n_rows; ++i) { MI_ASSERT(rows[i] >= 0 && rows[i] < logits->ne[1]); r.r[i] = rows[i]; }
+    if (logits->ne[0] <= 32*1024) k_topk<32><<<n_rows, 1024, 0, st>>>((const char *) logits->data, logits->ne[0], logits->nb[1], r, k, ids, vals);
+    else                          k_topk<64><<<n_rows, 1024, 0, st>>>((const char *) logits->data, logits->ne[0], logits->nb[1], r, k, ids, vals);
+}
+
 // ------------------------------------------------------------------ ROPE (mode NORM and NEOX, f32)
 struct rope_params {
     int n_dims; int mode; float freq_scale, ext_factor, attn_factor, theta_scale; float corr0, corr1;

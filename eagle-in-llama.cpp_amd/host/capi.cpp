@@ -50,6 +50,8 @@ EH_API void * eh_rope(void * c, void * a, void * pos, void * ff, int n_dims, int
     return ((Ctx *) c)->rope_ext((ggml_tensor *) a, (ggml_tensor *) pos, (ggml_tensor *) ff, n_dims, mode, n_ctx_orig, freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow);
 }
 EH_API void * eh_soft_max(void * c, void * a, void * mask, float scale, float max_bias) { return ((Ctx *) c)->soft_max_ext((ggml_tensor *) a, (ggml_tensor *) mask, scale, max_bias); }
+// k best entries of rows of a device tensor through the backend's top-k extension (0 = done, -1 = the backend has none / declines)
+EH_API int eh_top_k(void * c, void * t, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals) { return ((Ctx *) c)->be->top_k((ggml_tensor *) t, rows, n_rows, k, ids, vals) ? 0 : -1; }
 EH_API int  eh_alloc(void * c) { return ((Ctx *) c)->alloc() ? 0 : -1; }
 EH_API int  eh_compute(void * c) { return (int) ((Ctx *) c)->compute(); }
 EH_API void eh_set(void * c, void * t, const void * data, int64_t off, int64_t size) { ((Ctx *) c)->set((ggml_tensor *) t, data, (size_t) off, (size_t) size); }

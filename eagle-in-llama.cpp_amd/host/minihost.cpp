@@ -203,6 +203,13 @@ ggml_tensor * Ctx::soft_max_ext(ggml_tensor * a, ggml_tensor * mask, float scale
     return r;
 }
 
+bool Backend::top_k(const ggml_tensor * logits, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals) {
+    typedef int (*fn_t)(ggml_backend_t, const ggml_tensor *, const int32_t *, int, int, int32_t *, float *);
+    static const char * name = "ggml_backend_mi355x_top_k";
+    if (!reg || !reg->iface.get_proc_address) return false;
+    fn_t fn = (fn_t) reg->iface.get_proc_address(reg, name);
+    return fn && fn(be, logits, rows, n_rows, k, ids, vals) == 0;
+}
 bool Ctx::use_split(int main_device, const float * tensor_split) {
     if (!be->reg->iface.get_proc_address) return false;
     typedef ggml_backend_buffer_type_t (*fn_t)(int, const float *);

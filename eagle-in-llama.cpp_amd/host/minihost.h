@@ -39,6 +39,9 @@ struct Backend {
     ~Backend();
     const char * name() const;
     void set_n_threads(int n);                 // via get_proc_address("ggml_backend_set_n_threads") when offered
+    // k best entries of rows of a device tensor through the plugin's "ggml_backend_mi355x_top_k" extension; false when the backend has
+    // none (reference CPU backend) or declines the operands -- the caller then reads the rows back
+    bool top_k(const ggml_tensor * logits, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals);
     void synchronize();
     bool supports_op(const ggml_tensor * t) const;
     ggml_backend_buffer_t alloc_buffer(size_t size, int usage);

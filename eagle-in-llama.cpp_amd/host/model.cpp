@@ -545,9 +545,17 @@ int Model::decode(const Batch & b, bool want_hidden) {
         g.get_async(P.result_argmax, ids_stage.data(), 0, (size_t) n_outputs * 4);
         if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(P.result_norm, hidden.data(), 0, hidden.size() * 4); }
     } else if (st == GGML_STATUS_SUCCESS && P.head_here) {
-        logits.resize((size_t) n_outputs * cfg.n_vocab);
-        g.get_async(P.result_output, logits.data(), 0, logits.size() * 4);
-        if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(P.result_norm, hidden.data(), 0, hidden.size() * 4); }
+        topk_k = 0;
+        if (want_topk > 0 && n_outputs > 0) {          // the k best of every row, selected on the device: 8 k bytes per row come back instead of n_vocab floats
+            topk_ids.resize((size_t) n_outputs * want_topk); topk_vals.resize((size_t) n_outputs * want_topk);
+            if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(P.result_norm, hidden.data(), 0, hidden.size() * 4); }
+            if (be->top_k(P.result_output, nullptr, n_outputs, want_topk, topk_ids.data(), topk_vals.data())) { topk_k = want_topk; logits.clear(); }
+        }
+        if (!topk_k) {
+            logits.resize((size_t) n_outputs * cfg.n_vocab);
+            g.get_async(P.result_output, logits.data(), 0, logits.size() * 4);
+            if (want_hidden) { hidden.resize((size_t) n_outputs * E); g.get_async(P.result_norm, hidden.data(), 0, hidden.size() * 4); }
+        }
     } else { logits.clear(); hidden.clear(); }
     be->synchronize();
     const double t3 = now_us();
@@ -568,6 +576,11 @@ int Model::decode(const Batch & b, bool want_hidden) {
     return 0;
 }
 
+bool Model::topk_ith(int i, const int32_t ** ids, const float ** vals) const {
+    if (topk_k <= 0) return false;
+    for (int r = 0; r < n_outputs; ++r) if (out_ids[r] == i) { *ids = topk_ids.data() + (size_t) r * topk_k; *vals = topk_vals.data() + (size_t) r * topk_k; return true; }
+    return false;
+}
 int Model::argmax_ith(int i) const {
     for (int r = 0; r < n_outputs; ++r) if (out_ids[r] == i) {
         if (!argmax_ids.empty()) return argmax_ids[r];

@@ -91,6 +91,12 @@ struct Model {
     // greedy fast path: with want_logits = false decode() appends GGML_OP_ARGMAX to the graph and brings back one int per output
     // row (`argmax_ids`) instead of the logits rows; logits stays empty then
     bool want_logits = true;
+    // tree drafting: with want_topk = k > 0 (and want_logits) decode() asks the backend for the k best logits of every output row
+    // ("ggml_backend_mi355x_top_k") instead of downloading the rows; topk_ids / topk_vals [n_outputs][k] are valid when topk_k > 0,
+    // logits stays empty then.  A backend without the extension (reference CPU backend) leaves topk_k = 0 and delivers the logits.
+    int want_topk = 0, topk_k = 0;
+    std::vector<int32_t> topk_ids; std::vector<float> topk_vals;
+    bool topk_ith(int i, const int32_t ** ids, const float ** vals) const;       // by batch index
     std::vector<int32_t> argmax_ids;  // [n_outputs], valid after every decode on the rank that owns the LM head
     int argmax_ith(int i) const;      // by batch index; falls back to scanning logits when they were downloaded
     // timing / stats

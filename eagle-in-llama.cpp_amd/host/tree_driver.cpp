@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <set>
@@ -56,6 +58,18 @@ void candidates(const float * logits, int n_vocab, int top_k, float temp, std::v
     for (auto & c : out) c.p = (float)(c.p / sum);
 }
 
+// the same distribution from the k best (id, logit) pairs the device selected (descending, ties: lower id first -- the order of `better` above)
+void candidates_from_topk(const int32_t * ids, const float * vals, int k, float temp, std::vector<Cand> & out) {
+    out.clear();
+    for (int i = 0; i < k && ids[i] >= 0; ++i) out.push_back({ ids[i], vals[i], 0.0f });
+    if (out.empty()) return;
+    if (temp <= 0.0f) { out[0].p = 1.0f; return; }
+    const float mx = out[0].logit;
+    double sum = 0.0;
+    for (auto & c : out) { c.p = std::exp((c.logit - mx) / temp); sum += c.p; }
+    for (auto & c : out) c.p = (float)(c.p / sum);
+}
+
 struct SeqDraft {                         // struct seq_draft, speculative-eagle.cpp:16-30
     bool active = false, drafting = false, skip = false;
     int i_batch_dft = 0;
@@ -77,6 +91,7 @@ struct TreeSession {
     std::vector<SeqDraft> drafts;
     Batch batch_tgt, batch_dft;
     bool primed = false;                  // a target batch has been evaluated and waits for verification
+    bool dev_topk = true;                 // EH_HOST_TOPK=1: candidates from downloaded logits rows (the round-2 path)
     std::vector<Cand> dist_tgt;
 };
 
@@ -189,6 +204,7 @@ int tree_round(TreeSession & S, std::vector<int32_t> & out, double * st) {
     // ---------------------------------------------------------------- re-prime the draft with the sampled token (:488-495)
     const double t1 = now_us();
     D.want_logits = true;
+    D.want_topk = S.dev_topk ? std::max(1, std::min(S.top_k, std::min(V, 64))) : 0;      // the draft's candidates: k best per row, selected on the device when the backend can
     S.batch_dft.clear(); S.batch_dft.add(token_id, S.n_past_dft, 0, true); S.batch_dft.hidd = feat_tok;
     D.kv.seq_rm(0, S.n_past_dft, -1);
     int rc = D.decode(S.batch_dft, true);
@@ -207,10 +223,17 @@ int tree_round(TreeSession & S, std::vector<int32_t> & out, double * st) {
         for (int s = 0; s < n_seq_dft; ++s) {
             if (!drafts[s].drafting || drafts[s].skip) continue;
             std::vector<Cand> cur_p;
-            const float * lg = D.logits_ith(drafts[s].i_batch_dft);
             const float * hrow = D.hidden_ith(drafts[s].i_batch_dft);
-            if (!lg || !hrow) return -50;
-            candidates(lg, V, S.top_k, S.temp_dft, cur_p);
+            const int32_t * tk_ids; const float * tk_vals;
+            if (!hrow) return -50;
+            if (D.topk_ith(drafts[s].i_batch_dft, &tk_ids, &tk_vals)) candidates_from_topk(tk_ids, tk_vals, D.topk_k, S.temp_dft, cur_p);
+            else {
+                const float * lg = D.logits_ith(drafts[s].i_batch_dft);
+                if (!lg) return -50;
+                candidates(lg, V, S.top_k, S.temp_dft, cur_p);
+            }
+            { static const bool dbg = getenv("EH_TREE_DEBUG") != nullptr;
+              if (dbg) { fprintf(stderr, "[tree] depth %d branch %d:", i, s); for (int f = 0; f < 4 && f < (int) cur_p.size(); ++f) fprintf(stderr, " id %d logit %.3f p %.4f |", cur_p[f].id, cur_p[f].logit, cur_p[f].p); fprintf(stderr, "\n"); } }
             std::vector<int> sa(1, s);
             for (int f = 1; f < 8 && f < (int) cur_p.size(); ++f) {
                 if (n_seq_cur < n_seq_dft && cur_p[f].p > S.p_split) {
@@ -246,6 +269,7 @@ int tree_round(TreeSession & S, std::vector<int32_t> & out, double * st) {
         ++n_past_cur; st[TS_N_DRAFTED] += S.batch_dft.n_tokens();
         if (S.batch_tgt.n_tokens() > S.n_draft) break;
     }
+    D.want_topk = 0;
     const double t2 = now_us();
     st[TS_T_DRAFT_US] += t2 - t1;
     // ---------------------------------------------------------------- evaluate the tree on the target (:646-656)
@@ -276,6 +300,7 @@ EH_API void * eh_tree_begin(void * tgt, void * dft, const int32_t * prompt, int 
     S->tgt = (Model *) tgt; S->dft = (Model *) dft;
     S->n_seq_dft = std::max(1, std::min(ip[0], S->tgt->cfg.n_seq_max)); S->n_draft = ip[1]; S->top_k = ip[2]; S->rng.seed((unsigned) ip[3]);
     S->p_split = fp[0]; S->temp = fp[1]; S->temp_dft = fp[2];
+    S->dev_topk = getenv("EH_HOST_TOPK") == nullptr && S->top_k <= 64;
     if (tree_prompt(*S, prompt, n_prompt)) { delete S; return nullptr; }
     return S;
 }

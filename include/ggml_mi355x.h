@@ -23,7 +23,8 @@
  *   "ggml_backend_split_buffer_type"  (R/src/llama-model.cpp:310-322, -sm row)  -> ggml_backend_mi355x_split_buffer_type
  *   "ggml_backend_get_features"       (R/src/llama.cpp:12044)                    -> feature list
  * and one extension of ours, "ggml_backend_mi355x_stream": void * (*)(ggml_backend_t) -> the hipStream_t of a backend
- * instance, for hosts that enqueue RCCL collectives between graph segments (tensor parallel, host/tp.cpp).
+ * instance, for hosts that enqueue RCCL collectives between graph segments (tensor parallel, host/tp.cpp);
+ * and "ggml_backend_mi355x_top_k" (below) for hosts that draft token trees.
  */
 #ifndef GGML_MI355X_H
 #define GGML_MI355X_H
@@ -48,6 +49,14 @@ GGML_MI355X_API int                ggml_backend_mi355x_device_count(void);
 /* row-split (tensor-parallel) weight buffers, signature of ggml_backend_split_buffer_type_t
  * (R/ggml/include/ggml-backend.h:188); tensor_split has one entry per device, NULL => even split */
 GGML_MI355X_API ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device, const float * tensor_split);
+
+/* Device-side top-k for tree drafting: the reference's tree driver reads the k best candidates of every live branch from the sampler's
+ * sorted cur_p (R/common/speculative.cpp:257-272, R/examples/speculative/speculative-eagle.cpp:542-625) after llama_get_logits_ith has
+ * brought the whole row (n_vocab floats) to the host.  `logits`: f32 tensor [n_vocab <= 65536, n_outputs] in a device buffer of this plugin;
+ * rows: n_rows row indices (NULL: 0 .. n_rows-1); for every row the k <= 64 largest values in descending order, ties: the lower index first;
+ * ids / vals: HOST arrays [n_rows][k] (fewer than k entries in a row: id -1, value -inf).  Ordered behind everything already submitted to
+ * `backend`, returns when the results are on the host.  0 = ok, -1 = not supported for these operands (the caller keeps its host path). */
+GGML_MI355X_API int ggml_backend_mi355x_top_k(ggml_backend_t backend, const struct ggml_tensor * logits, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals);
 
 /* measurement hook (not part of the reference's interface): HIP-event timing of every quantised mat-vec launch
  * between begin/end, on the stream the kernels are launched on.  out[0] = kernel milliseconds, out[1] = algorithmic

@@ -125,6 +125,37 @@ def test_argmax_follows_the_reference_tie_rule(ea, gpu, ref_cpu):
     assert ref_argmax(np.asarray([[1.0, 3.0, 3.0, 2.0]]))[0] == 2
 
 
+def test_device_top_k_matches_host_candidates(ea, gpu, ref_cpu):
+    """The plugin's top-k extension (tree drafting, SURVEY 8 f1: R/common/speculative.cpp:257-272 takes the k best candidates per live branch)
+    against the host rule of host/tree_driver.cpp `candidates`: descending logit, ties -> LOWER id first.  Rows with ties across threads and
+    waves, -inf entries, fewer finite entries than k, k = 1 / 40 / 64, a row subset, vocabularies of 32000 and 50257 (two register tiers)."""
+    rng = np.random.default_rng(21)
+    def host_topk(row, k):
+        order = np.lexsort((np.arange(row.size), -row.astype(np.float64)))          # value descending, then index ascending
+        return order[:k].astype(np.int32), row[order[:k]]
+    for ne0, rows in [(32000, 10), (50257, 3), (777, 4), (40, 2)]:
+        x = rng.standard_normal((rows, ne0)).astype(np.float32)
+        x[0, [5 % ne0, 1029 % ne0, 2053 % ne0, 31 % ne0, 700 % ne0]] = 7.5          # one maximum in several threads / waves: ids ascending
+        if rows > 1: x[1, :] = -np.inf; x[1, [3, 9]] = [1.0, 2.0]          # two finite entries, then -inf in index order
+        if rows > 2: x[2, ne0 - 1] = 99.0; x[2, 0] = 99.0
+        g = ea.Graph(gpu); a = g.tensor(ea.F32, ne0, rows); b = g.scale(a, 1.0)
+        g.alloc(); g.set(a, x); g.compute()
+        for k in (1, 8, 40, 64):
+            if k > ne0: continue
+            ids, vals = g.top_k(b, k)
+            for r in range(rows):
+                wi, wv = host_topk(x[r], k)
+                assert np.array_equal(ids[r], wi), (ne0, r, k, ids[r][:8], wi[:8])
+                assert np.array_equal(vals[r], wv), (ne0, r, k)
+        sub = [rows - 1, 0]
+        ids, vals = g.top_k(b, 5, rows=sub)
+        for j, r in enumerate(sub):
+            assert np.array_equal(ids[j], host_topk(x[r], 5)[0])
+    # the reference CPU backend has no such extension: the host keeps its own path
+    g = ea.Graph(ref_cpu); a = g.tensor(ea.F32, 64, 2); g.alloc()
+    assert g.top_k(a, 4) is None
+
+
 def test_activation_edge_cases(ea, gpu):
     """all-zero activations, a zero super-block, +-max ties: quantised image must follow the CPU rule"""
     rng = np.random.default_rng(8)
