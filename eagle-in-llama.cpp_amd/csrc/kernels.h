@@ -62,6 +62,9 @@ bool mi_mmq_inline_quant(int type, int T, const mmvq_launch & L);      // the ke
 void mi_mmq_launch(hipStream_t st, int type, int T, const mmvq_launch & L);
 // tiled-layout kernel (kernels_mmt.hip): any token count, in-kernel activation quantiser for small T*k
 void mi_mmt_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L, mi_act_cache * cache, const void * key);
+// big batches (25+ tokens) as an int8 GEMM on 32x32x32 MFMA tiles (kernels_bb.hip); needs L.act.pre (whole-batch image), one matrix, plain f32 output
+bool mi_bb_supported(int type);
+void mi_bb_run(hipStream_t st, int type, int n_tokens, const mmvq_launch & L);
 // two launches over the same activations with weights of two types (Q4_K | Q5_K, then Q6_K) as one grid; <= 8 tokens, in-kernel quantiser
 bool mi_mmt_pair_supported(int typeA, int typeB, int T, const mmvq_launch & LA);
 void mi_mmt_run_pair(hipStream_t st, int typeA, int typeB, int T, const mmvq_launch & LA, const mmvq_launch & LB);

@@ -812,7 +812,7 @@ void mi_mmt_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_a
             L.m[0].out += (size_t) t0 * L.m[0].o_tok;
             if (L.m[0].res) L.m[0].res += (size_t) t0 * L.m[0].r_tok;
             L.act.pre = mmt_big_image(st, type, T, t0, L, cache, key);
-            mmt_bb_dispatch(st, type, T, L);
+            if (mi_bb_supported(type)) mi_bb_run(st, type, T, L); else mmt_bb_dispatch(st, type, T, L);      // (Q4_0, GGML_MI355X_BB_OLD=1: round 2's kernel)
         }
         return;
     }
