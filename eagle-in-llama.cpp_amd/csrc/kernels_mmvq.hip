@@ -393,6 +393,43 @@ __global__ void __launch_bounds__(512) k_quant_q8K(const act_src a, int k, char 
         quant_q8K_unit(v, lane, t, sb, k, nsb, q, d, bs, rec32, rec16);
     }
 }
+// Q8_0 images of any number of tokens in one launch, one wave per (token, 256-element chunk = 8 blocks of 32), same single memory
+// phase as k_quant_q8K.  (Round 2 filled such images 8 tokens per launch: nine launches per image at a 69-token verify batch, 30 % of
+// the GPU time of a Q8_0 tree round - profiles/r03_verify_kernel_stats.txt.)
+__global__ void __launch_bounds__(512) k_quant_q80(const act_src a, int k, char * out, int T) {
+    const int lane = threadIdx.x % WAVE, wave = threadIdx.x / WAVE;
+    const int nch = (k + 255) / 256, nb = k / 32, nu = T*nch;
+    int8_t * q = (int8_t *) out;
+    float  * d = (float *)(out + (size_t) T*k);
+    for (int u = blockIdx.x*8 + wave; u < nu; u += gridDim.x*8) {
+        const int t = u / nch, ch = u - t*nch, e = ch*256 + lane*4;
+        const float * row = a.X + (size_t) t*a.xs;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.norm) {
+            double s = 0.0;
+            for (int it0 = 0; it0*256 < k; it0 += 8) {
+                float4 x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int i = (it0 + j)*256 + lane*4; x[j] = i < k ? *(const float4 *)(row + i) : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s += (double)(x[j].x*x[j].x); s += (double)(x[j].y*x[j].y); s += (double)(x[j].z*x[j].z); s += (double)(x[j].w*x[j].w);
+                    if (it0 + j == ch) v = x[j];
+                }
+            }
+            const double tot = wave_sum_d(s);
+            const float mean = (float)(tot / (double) k), sc = 1.0f / sqrtf(mean + a.eps);
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            if (e < k) {
+                if (a.norm_w) { const float4 w = *(const float4 *)(a.norm_w + e); v.x *= w.x; v.y *= w.y; v.z *= w.z; v.w *= w.w; }
+                if (a.norm_out) *(float4 *)(a.norm_out + (size_t) t*a.norm_os + e) = v;
+            }
+        } else if (e < k) {
+            v = (a.X2 && e >= a.ksplit) ? *(const float4 *)(a.X2 + (size_t) t*a.xs2 + (e - a.ksplit)) : *(const float4 *)(row + e);
+        }
+        q80_unit(v, q + (size_t) t*k + e, d + (size_t) t*nb + e/32, lane, e < k);
+    }
+}
 template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src & a, int k, char * out, int Ttot, int t0) {
     if (KQ) {
         static const bool legacy = getenv("GGML_MI355X_QUANT_LEGACY") != nullptr;
@@ -415,7 +452,12 @@ void mi_quant_act(hipStream_t st, int type, int T, const act_src & a0, int k, ch
         k_quant_q8K<<<grid, 512, 0, st>>>(a0, k, out, T, 0, T);
         return;
     }
-    for (int t0 = 0; t0 < T; t0 += 8) {                       // images of more than 8 tokens (matrix-core kernel) are filled 8 tokens per launch
+    if (mi_traits(type).blck == 32 && !legacy && k % 4 == 0) {
+        const int nu = T * ((k + 255)/256); int grid = (nu + 7) / 8; if (grid > 1024) grid = 1024;
+        k_quant_q80<<<grid, 512, 0, st>>>(a0, k, out, T);
+        return;
+    }
+    for (int t0 = 0; t0 < T; t0 += 8) {                       // GGML_MI355X_QUANT_LEGACY: 8 tokens per launch (round 1)
         act_src a = a0; a.X += (size_t) t0 * a.xs;
         if (a.X2) a.X2 += (size_t) t0 * a.xs2;                 // the second CONCAT source advances with the tokens too
         if (a.norm_out) a.norm_out += (size_t) t0 * a.norm_os;
