@@ -20,6 +20,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "lib")
 PLUGIN_PATH = os.environ.get("EAGLE_MI355X_PLUGIN") or os.path.join(LIB, "libggml-mi355x.so")     # (override: A/B of compile-time variants)
+if os.environ.get("EH_LAB_PLUGIN"):          # scripts/ only: the diagnostic build (build.py --lab) with the A/B knobs and phase-stamp kernels
+    PLUGIN_PATH = PLUGIN_PATH.replace("libggml-mi355x.so", "libggml-mi355x-lab.so")
 HOST_PATH = os.path.join(LIB, "libeagle_host.so")
 
 # ggml enums (include/ggml_abi.h)
@@ -40,7 +42,7 @@ class PluginMissing(RuntimeError):
 def require_plugin():
     """The product path never falls back to a CPU implementation: no plugin => error."""
     if not os.path.exists(PLUGIN_PATH):
-        raise PluginMissing(f"{PLUGIN_PATH} not built -- run `python {HERE}/build.py` (hipcc, gfx950)")
+        raise PluginMissing(f"{PLUGIN_PATH} not built -- run `python {HERE}/build.py` (hipcc, gfx950; `--lab` for the diagnostic variant)")
     return PLUGIN_PATH
 
 

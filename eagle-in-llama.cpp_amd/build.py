@@ -53,12 +53,15 @@ def _build_objs(srcs, objdir, flags, force):
     return objs, bool(procs)
 
 
-def build_plugin(force=False):
+def build_plugin(force=False, lab=False):
+    """lab=True: the diagnostic variant (-DMI_LAB: A/B knobs read from the environment, phase-stamp kernel instantiations) as
+    lib/libggml-mi355x-lab.so, for scripts/ only; the shipped plugin carries neither."""
     os.makedirs(LIB, exist_ok=True)
     srcs = sorted(glob.glob(f"{HERE}/csrc/*.hip") + glob.glob(f"{HERE}/csrc/*.cpp"))
-    flags = COMMON + [f"--offload-arch={ARCH}", "-x", "hip"]
-    objs, changed = _build_objs(srcs, os.path.join(LIB, "obj-plugin"), flags, force)
-    out = os.path.join(LIB, "libggml-mi355x.so")
+    # -fno-strict-aliasing: kernels view LDS / registers through several types (f16 probabilities over an fp32 score row, packed int8 in int32)
+    flags = COMMON + [f"--offload-arch={ARCH}", "-x", "hip", "-fno-strict-aliasing"] + (["-DMI_LAB=1"] if lab else [])
+    objs, changed = _build_objs(srcs, os.path.join(LIB, "obj-plugin-lab" if lab else "obj-plugin"), flags, force)
+    out = os.path.join(LIB, "libggml-mi355x-lab.so" if lab else "libggml-mi355x.so")
     if changed or not os.path.exists(out):
         _run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs + ["-ldl", "-lpthread"])
     return out
@@ -100,4 +103,7 @@ def build_all(force=False):
 
 
 if __name__ == "__main__":
-    print(build_all("--force" in sys.argv))
+    if "--lab" in sys.argv:
+        print(build_plugin("--force" in sys.argv, lab=True))
+    else:
+        print(build_all("--force" in sys.argv))

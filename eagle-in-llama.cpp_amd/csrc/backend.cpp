@@ -18,7 +18,6 @@
 #include <dlfcn.h>
 #include "tile_layout.h"
 
-#define MI_MAX_DEVICES 16
 
 // The host's own constructor for buffer objects (R/ggml/src/ggml-backend.cpp "ggml_backend_buffer_init").
 // Resolved from the process that loaded us when it is a ggml host, so that the object is created and
@@ -45,6 +44,7 @@ static void set_device(int dev) { HIP_CHECK(hipSetDevice(dev)); }
 ggml_backend_buffer_t mi_make_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * ctx, size_t size) { return make_buffer(buft, iface, ctx, size); }
 int mi_device_count() { return g_ndev; }
 ggml_backend_dev_t mi_device(int i) { return (i >= 0 && i < g_ndev) ? &g_devs[i] : nullptr; }
+int mi_device_ordinal(int i) { return (i >= 0 && i < g_ndev) ? g_devctx[i].device : -1; }
 
 // ============================================================ weight re-layout state (tile_layout.h, kernels_tile.hip)
 // A quantised weight matrix keeps ggml's row-major blocks until the first MUL_MAT that reads it; mi_ensure_tiled() then permutes
@@ -238,6 +238,7 @@ static void be_free(ggml_backend_t b) {
     if (c->scratch) HIP_CHECK(hipFree(c->scratch));
     if (c->act_cache) { if (c->act_cache->pool) HIP_CHECK(hipFree(c->act_cache->pool)); if (c->act_cache->big_pool) HIP_CHECK(hipFree(c->act_cache->big_pool)); if (c->act_cache->rope_tab) HIP_CHECK(hipFree(c->act_cache->rope_tab)); delete c->act_cache; }
     if (c->copy_ev) HIP_CHECK(hipEventDestroy(c->copy_ev));
+    mi_split_free_events(c);
     HIP_CHECK(hipStreamDestroy(c->stream));
     delete c; delete b;
 }
@@ -343,7 +344,7 @@ static ggml_backend_t dev_init_backend(ggml_backend_dev_t d, const char *) {
     b->guid = &g_guid; b->iface = g_be_iface; b->device = d; b->context = c;
     return b;
 }
-static ggml_backend_buffer_type_t dev_buft(ggml_backend_dev_t d) { return &g_bufts[((mi_device_ctx *) d->context)->device]; }
+static ggml_backend_buffer_type_t dev_buft(ggml_backend_dev_t d) { return &g_bufts[d - g_devs]; }
 static ggml_backend_buffer_type_t dev_host_buft(ggml_backend_dev_t) { return &g_host_buft; }
 static bool dev_supports_op(ggml_backend_dev_t d, const ggml_tensor * op) { return mi_supports_op(((mi_device_ctx *) d->context)->device, op); }
 static bool dev_supports_buft(ggml_backend_dev_t d, ggml_backend_buffer_type_t t) {
@@ -432,12 +433,12 @@ static void init_once() {
             if (hipGetDeviceProperties(&p, i) != hipSuccess) { (void) hipGetLastError(); continue; }
             // code objects are gfx950 only: refuse anything else instead of failing at first launch
             if (strncmp(p.gcnArchName, "gfx950", 6) != 0) { MI_LOG("device %d is %s, not gfx950 -- skipped", i, p.gcnArchName); continue; }
-            mi_device_ctx & d = g_devctx[i];
+            mi_device_ctx & d = g_devctx[kept];              // all three tables by the LOGICAL index (kept devices); d.device = the HIP ordinal
             d.device = i;
             snprintf(d.name, sizeof(d.name), "MI355X%d", i);
             snprintf(d.desc, sizeof(d.desc), "%s (%s, %d CUs, %.0f GiB)", p.name, p.gcnArchName, p.multiProcessorCount, p.totalGlobalMem / 1073741824.0);
             g_devs[kept].iface = g_dev_iface; g_devs[kept].reg = &g_reg; g_devs[kept].context = &d;
-            g_bufts[i].iface = g_buft_iface; g_bufts[i].device = &g_devs[kept]; g_bufts[i].context = nullptr;
+            g_bufts[kept].iface = g_buft_iface; g_bufts[kept].device = &g_devs[kept]; g_bufts[kept].context = nullptr;
             ++kept;
         }
         g_ndev = kept;

@@ -228,7 +228,14 @@ static bool can_defer_norm(const gctx & c, int i) {
         found++;
     }
     if (found != nu || n_mv == 0) return false;
-    if (wanted) for (int j = c.idx(x) + 1; j <= last; ++j) { const ggml_tensor * t = c.g->nodes[j]; if (is_mv(t) && !mi_ensure_tiled(t->src[0])) return false; }
+    // Every launch that folds a norm writes the normalised tensor as a side effect, wanted here or not: this graph may be one of the
+    // scheduler's views, and a reader in the NEXT view (a cut between wq and wk) is invisible from here.  Only tiled launches do
+    // that (one block writes, kernels_mmt.hip), so a fold needs every mat-vec reader tiled.
+    (void) wanted;
+    for (int j = c.idx(x) + 1; j <= last; ++j) { const ggml_tensor * t = c.g->nodes[j]; if (is_mv(t) && !mi_ensure_tiled(t->src[0])) return false; }
+    // the materialised tensor must not land on the rows the other blocks of the same launch are still reading (a bare RMS_NORM
+    // that ggml-alloc placed in place over its single-use input; with a MUL behind it the scan below catches the MUL at i + 1)
+    if (overlap(x->data, mi_nbytes(x), a->data, mi_nbytes(a))) return false;
     if (c.root_last_read(a) <= last) {
         // `a` is not read after the last consumer: its memory may already have been handed to a node in between
         std::vector<char> none(c.n, 0);
@@ -271,7 +278,7 @@ static bool rope_fusable(const ggml_tensor * r, const ggml_tensor * mm) {
     return true;
 }
 // follow mm's result: [RESHAPE] -> ROPE -> (CPY to f16 cache)?  |  [TRANSPOSE] -> CPY f16  |  ADD residual  |  plain
-static bool rowsel_fuse_on() { static const bool v = getenv("GGML_MI355X_NO_ROWSEL_FUSE") == nullptr; return v; }     // A/B: output-row selection / arg-max row fetch fused
+static bool rowsel_fuse_on() { static const bool v = mi_lab_env("GGML_MI355X_NO_ROWSEL_FUSE") == nullptr; return v; }     // A/B: output-row selection / arg-max row fetch fused
 static void plan_member(const gctx & c, member & m, bool allow_ids) {
     const ggml_tensor * mm = m.mm;
     m.epi = EPI_F32; m.out = mm; m.res = nullptr; m.relu = false; m.rope = nullptr; m.ids = nullptr; m.swallowed.clear();
@@ -402,7 +409,8 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
                     if (write_conflicts(c, mul->data, mi_nbytes(mul), at, upto, skip)) break;
                     if (overlap(mul->data, mi_nbytes(mul), ap.src.X, (size_t) T * ap.src.xs * 4)) break;
                     mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = 2; L.swiglu = 1; L.tiled = tiled0;
-                    if (tiled0 && ap.rms) { L.act.norm_out = (float *) x->data; L.act.norm_os = x->nb[1]/4; }      // the folded norm is materialised as a side effect
+                    MI_ASSERT(tiled0 || !ap.rms);
+                    if (ap.rms && !overlap(mul->data, mi_nbytes(mul), x->data, mi_nbytes(x))) { L.act.norm_out = (float *) x->data; L.act.norm_os = x->nb[1]/4; }      // the folded norm is materialised as a side effect
                     member g0 = mem[0], g1 = mem[q]; g0.epi = EPI_F32; g0.out = mul; g0.res = nullptr; g1.epi = EPI_F32; g1.out = mul; g1.res = nullptr;
                     fill_mat(L.m[0], g0); fill_mat(L.m[1], g1);
                     L.m[0].o_row = 4; L.m[0].o_tok = mul->nb[1];
@@ -439,7 +447,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
             std::vector<char> sk = skip; sk[m.node] = 1; for (int s : m.swallowed) sk[s] = 1;
             const int orig = m.swallowed.empty() ? m.node : std::max(m.node, *std::max_element(m.swallowed.begin(), m.swallowed.end()));
             const size_t nb = mi_nbytes(m.out);
-            static const bool dbg = getenv("GGML_MI355X_DEBUG_GROUP") != nullptr;
+            static const bool dbg = mi_lab_env("GGML_MI355X_DEBUG_GROUP") != nullptr;
             if (write_conflicts(c, m.out->data, nb, i, orig, sk)) { if (dbg) MI_LOG("group at %s: member %s not hoisted (write conflict, epi %d, out %s)", t->name, m.mm->name, m.epi, m.out->name); continue; }   // leave it to run at its own position
             if (overlap(m.out->data, nb, ap.src.X, (size_t) T * ap.src.xs * 4) || (ap.src.X2 && overlap(m.out->data, nb, ap.src.X2, (size_t) T * ap.src.xs2 * 4))) { if (dbg) MI_LOG("group at %s: member %s not hoisted (overlaps activations)", t->name, m.mm->name); continue; }
         }
@@ -455,7 +463,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
         }
         if (clash) { mi_op_concat(st, x); ap.src.X = (const float *) x->data; ap.src.xs = x->nb[1]/4; ap.src.X2 = nullptr; ap.src.xs2 = 0; ap.src.ksplit = 0; }
     }
-    { static const bool dbg = getenv("GGML_MI355X_DEBUG_GROUP") != nullptr; if (dbg) MI_LOG("group at %s: %d siblings, %d kept, T=%d", t->name, nm, keep, T); }
+    { static const bool dbg = mi_lab_env("GGML_MI355X_DEBUG_GROUP") != nullptr; if (dbg) MI_LOG("group at %s: %d siblings, %d kept, T=%d", t->name, nm, keep, T); }
     mmvq_launch L{}; L.act = ap.src; L.k = k; L.n_mat = 0; L.swiglu = 0; L.tiled = tiled0;
     if (tiled0 && ap.rms) { L.act.norm_out = (float *) x->data; L.act.norm_os = x->nb[1]/4; }
     if (rope0) {
@@ -466,7 +474,7 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
         // Every layer of a forward pass rotates by the same positions: when this graph holds at least four ROPE nodes (two layers) over these positions the
         // {cos, sin} values are computed once (a 4 us launch) instead of in every epilogue of every layer (theta by a recurrence of up to 63
         // dependent multiplies, then sinf / cosf: ~4 us per q|k|v launch at 6 tokens).  A chain step's single layer keeps the in-epilogue form.
-        static const bool tab_on = getenv("GGML_MI355X_NO_ROPE_TABLE") == nullptr;
+        static const bool tab_on = mi_lab_env("GGML_MI355X_NO_ROPE_TABLE") == nullptr;
         mi_act_cache * ac = ctx->act_cache;
         // positions may be a slice of a longer tensor (the draft chain keeps the positions of all its steps in one input and hands every step a
         // view): the table covers the root, a launch reads its rows
@@ -490,6 +498,9 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
             } else L.rope.tab = rows;
         }
     }
+    MI_ASSERT(tiled0 || !ap.rms);                                          // can_defer_norm: a fold needs tiled readers
+    // a member whose (hoisted) output shares memory with the norm tensor: that memory has been handed on, nobody reads the norm any more
+    for (int q = 0; q < keep; ++q) if (L.act.norm_out && sel[q].out && overlap(sel[q].out->data, mi_nbytes(sel[q].out), x->data, mi_nbytes(x))) L.act.norm_out = nullptr;
     mmvq_launch LB = L; LB.act.norm_out = nullptr;                         // the second type's partition of a mixed-type launch
     for (int q = 0; q < keep; ++q) { mmvq_launch & D = sel[q].alt ? LB : L; fill_mat(D.m[D.n_mat++], sel[q]); }
     const void * key = ap.rms ? (const void *) ap.rms : (const void *) x;
@@ -555,7 +566,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
         if (c.done[i] || is_view_op(t->op) || mi_nelements(t) == 0) continue;
         ggml_tensor * nx = (i + 1 < n) ? g->nodes[i + 1] : nullptr;
         const bool single_use = fuse && c.n_uses(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
-        { static const bool trace = getenv("GGML_MI355X_TRACE_OPS") != nullptr; if (trace) MI_LOG("node %4d op %2d %-24s [%lld %lld %lld] src0 %s src1 %s", i, (int) t->op, t->name, (long long) t->ne[0], (long long) t->ne[1], (long long) t->ne[2], t->src[0] ? t->src[0]->name : "-", t->src[1] ? t->src[1]->name : "-"); }
+        { static const bool trace = mi_lab_env("GGML_MI355X_TRACE_OPS") != nullptr; if (trace) MI_LOG("node %4d op %2d %-24s [%lld %lld %lld] src0 %s src1 %s", i, (int) t->op, t->name, (long long) t->ne[0], (long long) t->ne[1], (long long) t->ne[2], t->src[0] ? t->src[0]->name : "-", t->src[1] ? t->src[1]->name : "-"); }
 
         switch (t->op) {
             case GGML_OP_RMS_NORM: {

@@ -237,10 +237,11 @@ template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_at
     }
     attn_stamp<STAMP>(7);
 }
+#ifdef MI_LAB          // the STAMP = true instantiation and its plumbing exist in the lab build only (build.py --lab)
 static unsigned long long * g_attn_stamp_dev = nullptr;
 static bool attn_stamps_on() {
     static const bool on = [] {
-        if (!getenv("GGML_MI355X_ATTN_STAMPS")) return false;
+        if (!mi_lab_env("GGML_MI355X_ATTN_STAMPS")) return false;
         const size_t n = (size_t) 512 * 4 * 8 * 8;
         HIP_CHECK(hipMalloc((void **) &g_attn_stamp_dev, n)); HIP_CHECK(hipMemset(g_attn_stamp_dev, 0, n));
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &g_attn_stamp_dev, sizeof(void *)));
@@ -254,6 +255,7 @@ extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_attn_s
     HIP_CHECK(hipMemcpy(out, g_attn_stamp_dev, (size_t) 512 * 4 * 8 * 8, hipMemcpyDeviceToHost));
     return 512 * 4 * 8;
 }
+#endif
 
 static int attn_tokens_per_block(const mi_attn_args & a) { return (a.T > 8 && attn_lds_bytes(a.n_kv, 16) <= 150*1024) ? 16 : 8; }
 
@@ -276,11 +278,13 @@ void mi_op_attn_small(hipStream_t st, const mi_attn_args & a) {
     int dsplit = (a.H * tiles >= 256) ? ntile/4 : ((a.H * tiles >= 128) ? ntile/2 : ntile);
     if (dsplit < 1) dsplit = 1;
     const dim3 grid(a.H, tiles, dsplit);
+#ifdef MI_LAB
     if (a.d == 128 && attn_stamps_on()) {
         mi_allow_big_lds((const void *) k_attn_small<128, true>);
         k_attn_small<128, true><<<grid, 256, lds, st>>>(a, tt);
         return;
     }
+#endif
     mi_allow_big_lds(a.d == 128 ? (const void *) k_attn_small<128> : (const void *) k_attn_small<64>);
     if (a.d == 128) k_attn_small<128><<<grid, 256, lds, st>>>(a, tt);
     else            k_attn_small<64><<<grid, 256, lds, st>>>(a, tt);

@@ -245,7 +245,7 @@ template <int TYPE> static void bb_launch(hipStream_t st, int T, const mmvq_laun
     mi_prof_end(st, pi);
 }
 bool mi_bb_supported(int type) {
-    static const bool old = getenv("GGML_MI355X_BB_OLD") != nullptr;          // A/B: round 2's 16 x 8 accumulator kernel for every type
+    static const bool old = mi_lab_env("GGML_MI355X_BB_OLD") != nullptr;          // A/B: round 2's 16 x 8 accumulator kernel for every type
     return !old && (type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K || type == GGML_TYPE_Q8_0);
 }
 void mi_bb_run(hipStream_t st, int type, int T, const mmvq_launch & L) {

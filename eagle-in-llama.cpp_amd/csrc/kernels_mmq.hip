@@ -197,7 +197,7 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
         if (lds > 48*1024) mi_allow_big_lds(fn);
         int nb = 0;
         HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds));
-        if (getenv("GGML_MI355X_DEBUG_OCC")) fprintf(stderr, "[mi355x] occupancy fn=%p threads=%d lds=%zu -> %d blocks/CU\n", fn, threads, lds, nb);
+        if (mi_lab_env("GGML_MI355X_DEBUG_OCC")) fprintf(stderr, "[mi355x] occupancy fn=%p threads=%d lds=%zu -> %d blocks/CU\n", fn, threads, lds, nb);
         if (nb < 1) nb = 1;
         g_lds[fn] = lds; g_occ[fn] = nb;
     }
@@ -205,7 +205,7 @@ static int blocks_per_cu(const void * fn, int threads, size_t lds) {
 }
 
 // tuning knob (experiments only): GGML_MI355X_MMQ_CFG bit 0 = single-buffered fragments everywhere, bit 1 = never 16-wave blocks, bit 2 = one block per row group
-static int mmq_cfg() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMQ_CFG"); return e ? atoi(e) : 0; }(); return v; }
+static int mmq_cfg() { static const int v = [] { const char * e = mi_lab_env("GGML_MI355X_MMQ_CFG"); return e ? atoi(e) : 0; }(); return v; }
 
 template <int TYPE, bool DUAL, int NW, bool PF, int TG> static void mmq_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
     const size_t lds = mmq_lds_bytes(T, L.k, NW, DUAL, TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0);
@@ -252,7 +252,7 @@ template <int TYPE> static void mmq_launch_type(hipStream_t st, int T, const mmv
 // verification it costs more than the launch it saves (951 vs 1015 tokens/s at 8 units per wave: every block of wo / qkv repeats
 // the quantisation).  Mirrors the block shape mmq_launch_type picks (16 waves for single-matrix launches with <= 256 row groups).
 bool mi_mmq_inline_quant(int type, int T, const mmvq_launch & L) {
-    static const int upw = [] { const char * e = getenv("GGML_MI355X_MMQ_INLINE_UPW"); return e ? atoi(e) : 0; }();
+    static const int upw = [] { const char * e = mi_lab_env("GGML_MI355X_MMQ_INLINE_UPW"); return e ? atoi(e) : 0; }();
     if (upw <= 0 || !(type == GGML_TYPE_Q4_K || type == GGML_TYPE_Q5_K || type == GGML_TYPE_Q6_K)) return false;
     if (T > 8 || L.act.X2 || L.k > 8192) return false;
     int total = 0;

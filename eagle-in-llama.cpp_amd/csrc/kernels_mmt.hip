@@ -497,10 +497,11 @@ static int device_cus() {
     return n;
 }
 static void ensure_attr(const void * fn) { mi_allow_big_lds(fn); }
+#ifdef MI_LAB          // the STAMP = true instantiations and their plumbing exist in the lab build only (build.py --lab)
 static unsigned long long * g_stamp_host_ptr = nullptr;
 static bool mmt_stamps_on() {
     static const bool on = [] {
-        if (!getenv("GGML_MI355X_MMT_STAMPS")) return false;
+        if (!mi_lab_env("GGML_MI355X_MMT_STAMPS")) return false;
         const size_t n = (size_t) 4 * 256 * 16 * MMT_NSTAMP * 8;
         HIP_CHECK(hipMalloc((void **) &g_stamp_host_ptr, n)); HIP_CHECK(hipMemset(g_stamp_host_ptr, 0, n));
         HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_mmt_stamps), &g_stamp_host_ptr, sizeof(void *)));
@@ -516,9 +517,10 @@ extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_mmt_st
     HIP_CHECK(hipMemcpy(out, g_stamp_host_ptr, n * 8, hipMemcpyDeviceToHost));
     return (int) n;
 }
-static bool mmt_dual_pf() { static const bool v = getenv("GGML_MI355X_MMT_DUAL_PF") != nullptr; return v; }      // A/B: double-buffered fragments in the gate|up launch
-static int mmt_pfpos() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_PFPOS"); return e ? atoi(e) : 2; }(); return v; }   // 0 behind the activation loads | 1 behind the partial sums | 2 once the norm scale is known
-static int mmt_nbuf() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_NBUF"); return e ? atoi(e) : 2; }(); return v; }
+#endif
+static bool mmt_dual_pf() { static const bool v = mi_lab_env("GGML_MI355X_MMT_DUAL_PF") != nullptr; return v; }      // A/B: double-buffered fragments in the gate|up launch
+static int mmt_pfpos() { static const int v = [] { const char * e = mi_lab_env("GGML_MI355X_MMT_PFPOS"); return e ? atoi(e) : 2; }(); return v; }   // 0 behind the activation loads | 1 behind the partial sums | 2 once the norm scale is known
+static int mmt_nbuf() { static const int v = [] { const char * e = mi_lab_env("GGML_MI355X_MMT_NBUF"); return e ? atoi(e) : 2; }(); return v; }
 
 template <int TYPE, bool DUAL, bool PF, int TG> static void mmt_launch_one(hipStream_t st, int T, const mmvq_launch & L) {
     constexpr int NW = TG == 1 ? 16 : 8;
@@ -530,9 +532,10 @@ template <int TYPE, bool DUAL, bool PF, int TG> static void mmt_launch_one(hipSt
     if (DUAL) total = L.m[0].rows / 16;
     else for (int i = 0; i < L.n_mat; ++i) total += L.m[i].rows / 16;
     if (total < 1) return;
-    static int launch_id = 0;
+#ifdef MI_LAB
     if constexpr (TG == 1) {
         if (mmt_stamps_on()) {
+            static int launch_id = 0;                                    // (lab runs are single-threaded)
             auto sfn = k_mmt<TYPE, DUAL, PF, TG, NW, true>;
             ensure_attr((const void *) sfn);
             const int sgrid = total < device_cus() ? total : device_cus();
@@ -540,6 +543,7 @@ template <int TYPE, bool DUAL, bool PF, int TG> static void mmt_launch_one(hipSt
             return;
         }
     }
+#endif
     auto fn = k_mmt<TYPE, DUAL, PF, TG, NW>;
     ensure_attr((const void *) fn);
     const int slots = device_cus() * (NW == 16 ? 1 : ((2*lds <= 160*1024) ? 2 : 1));
@@ -580,8 +584,8 @@ static int mmt_max_tokens(int type, int k, bool swiglu) {
     return t;
 }
 static bool mmt_inline_quant(int T, const mmvq_launch & L) {
-    static const bool off = getenv("GGML_MI355X_MMT_NO_INLINE") != nullptr;
-    static const int maxsb = [] { const char * e = getenv("GGML_MI355X_MMT_INLINE_MAXSB"); return e ? atoi(e) : 3; }();   // super-blocks per wave the in-kernel quantiser may take
+    static const bool off = mi_lab_env("GGML_MI355X_MMT_NO_INLINE") != nullptr;
+    static const int maxsb = [] { const char * e = mi_lab_env("GGML_MI355X_MMT_INLINE_MAXSB"); return e ? atoi(e) : 3; }();   // super-blocks per wave the in-kernel quantiser may take
     if (off || T > 8) return false;
     if (L.act.X2 && (L.act.ksplit % 256)) return false;
     const int per_wave = (L.k/256 + 15) / 16;
@@ -707,7 +711,7 @@ __global__ void __launch_bounds__(1024 / TGW) k_mmt_bb(const mmvq_launch L, cons
         }
     }
 }
-static int mmt_bb_tgw() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_BB_TGW"); const int t = e ? atoi(e) : 1; return (t == 1 || t == 2 || t == 4) ? t : 1; }(); return v; }
+static int mmt_bb_tgw() { static const int v = [] { const char * e = mi_lab_env("GGML_MI355X_MMT_BB_TGW"); const int t = e ? atoi(e) : 1; return (t == 1 || t == 2 || t == 4) ? t : 1; }(); return v; }
 template <int TYPE> static void mmt_bb_launch(hipStream_t st, int T, const mmvq_launch & L) {
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int DN = Q80 ? 8 : 1;
@@ -733,7 +737,7 @@ static void mmt_bb_dispatch(hipStream_t st, int type, int T, const mmvq_launch &
         default: MI_ABORT("mmt_bb: unsupported weight type %d", type);
     }
 }
-static int mmt_bb_min_tokens() { static const int v = [] { const char * e = getenv("GGML_MI355X_MMT_BB_MIN_T"); return e ? atoi(e) : 25; }(); return v; }
+static int mmt_bb_min_tokens() { static const int v = [] { const char * e = mi_lab_env("GGML_MI355X_MMT_BB_MIN_T"); return e ? atoi(e) : 25; }(); return v; }
 // image of a whole big batch (all of k): a ring of 4 x 8 MiB slots next to the small-image ring, keyed like it
 #define MI_BIG_SLOTS 4
 #define MI_BIG_SLOT_BYTES ((size_t) 8 << 20)
@@ -763,7 +767,7 @@ static const char * mmt_image(hipStream_t st, int type, int T, int t0, const mmv
     return cache->pool + (size_t) hit * cache->slot_bytes;
 }
 
-static bool mmt_pair_off() { static const bool v = getenv("GGML_MI355X_MMT_NO_PAIR") != nullptr; return v; }
+static bool mmt_pair_off() { static const bool v = mi_lab_env("GGML_MI355X_MMT_NO_PAIR") != nullptr; return v; }
 bool mi_mmt_pair_supported(int typeA, int typeB, int T, const mmvq_launch & LA) {
     if (mmt_pair_off() || T < 1 || T > 8 || typeB != GGML_TYPE_Q6_K || !(typeA == GGML_TYPE_Q4_K || typeA == GGML_TYPE_Q5_K)) return false;
     if (!mmt_inline_quant(T, LA)) return false;                       // both bodies quantise in their prologue (same activations, same k)

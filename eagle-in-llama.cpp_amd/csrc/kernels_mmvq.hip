@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(512) k_quant_q80(const act_src a, int k, char 
 }
 template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src & a, int k, char * out, int Ttot, int t0) {
     if (KQ) {
-        static const bool legacy = getenv("GGML_MI355X_QUANT_LEGACY") != nullptr;
+        static const bool legacy = mi_lab_env("GGML_MI355X_QUANT_LEGACY") != nullptr;
         if (!legacy) { const int nu = T * (k/256); int grid = (nu + 7) / 8; if (grid > 512) grid = 512; k_quant_q8K<<<grid, 512, 0, st>>>(a, k, out, Ttot, t0, T); return; }
     }
     const int units = T * ((k + 255) / 256);
@@ -446,7 +446,7 @@ template <bool KQ> static void quant_act_T(hipStream_t st, int T, const act_src 
 }
 size_t mi_act_image_bytes(int type, int T, int k) { return (act_img_bytes_full(mi_traits(type).blck == 256, T, k) + 255) & ~(size_t) 255; }
 void mi_quant_act(hipStream_t st, int type, int T, const act_src & a0, int k, char * out) {
-    static const bool legacy = getenv("GGML_MI355X_QUANT_LEGACY") != nullptr;
+    static const bool legacy = mi_lab_env("GGML_MI355X_QUANT_LEGACY") != nullptr;
     if (mi_traits(type).blck == 256 && !legacy) {             // one wave per (token, super-block): any number of tokens in one launch
         const int nu = T * (k/256); int grid = (nu + 7) / 8; if (grid > 1024) grid = 1024;
         k_quant_q8K<<<grid, 512, 0, st>>>(a0, k, out, T, 0, T);
@@ -615,7 +615,7 @@ int mi_mmvq_max_tokens(int type, int k) {
 static const int PRE_MIN_ELEMS = 8192;      // T*k above this: quantise once
 // K-quants with >= this many tokens go to the matrix-core kernel (kernels_mmq.hip); GGML_MI355X_MMQ_MIN_T overrides (0 = never)
 static int mmq_min_tokens() {
-    static const int v = [] { const char * e = getenv("GGML_MI355X_MMQ_MIN_T"); const int n = e ? atoi(e) : 2; return n <= 0 ? 1 << 30 : n; }();
+    static const int v = [] { const char * e = mi_lab_env("GGML_MI355X_MMQ_MIN_T"); const int n = e ? atoi(e) : 2; return n <= 0 ? 1 << 30 : n; }();
     return v;
 }
 void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_act_cache * cache, const void * key) {
@@ -686,7 +686,7 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
             }
             L.act.pre = cache->pool + (size_t) hit * cache->slot_bytes;
         }
-        { static const bool dbg = getenv("GGML_MI355X_DEBUG_MMQ") != nullptr; if (dbg) fprintf(stderr, "[mi355x] mat-vec type %d T %d (of %d, tmax %d) k %d -> %s\n", type, T, Ttot, tmax, L.k, mmq ? "mmq" : "mmvq"); }
+        { static const bool dbg = mi_lab_env("GGML_MI355X_DEBUG_MMQ") != nullptr; if (dbg) fprintf(stderr, "[mi355x] mat-vec type %d T %d (of %d, tmax %d) k %d -> %s\n", type, T, Ttot, tmax, L.k, mmq ? "mmq" : "mmvq"); }
         if (mmq) { mi_mmq_launch(st, type, T, L); continue; }
         switch (type) {
             case GGML_TYPE_Q4_K: launch_type<GGML_TYPE_Q4_K>(st, T, L); break;

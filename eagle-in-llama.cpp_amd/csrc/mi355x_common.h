@@ -78,6 +78,16 @@ static inline bool mi_same_shape(const ggml_tensor * a, const ggml_tensor * b) {
 static inline float   mi_op_f32(const ggml_tensor * t, int i) { float v; memcpy(&v, &t->op_params[i], 4); return v; }
 static inline int32_t mi_op_i32(const ggml_tensor * t, int i) { return t->op_params[i]; }
 
+#define MI_MAX_DEVICES 16
+// Lab switches.  The shipped plugin is built WITHOUT -DMI_LAB: mi_lab_env() is then a constant nullptr, the A/B knobs read through it fold to
+// their defaults and the diagnostic kernel instantiations (phase stamps) are not in the code object.  `python eagle-in-llama.cpp_amd/build.py --lab`
+// builds the lab variant (lib/libggml-mi355x-lab.so) that scripts/ab_bench.py, mmt_stamps.py, attn_stamps.py ... load.
+// Product settings stay plain getenv: GGML_MI355X_NO_FUSION, _NO_TILE, _SYNC_SPIN, _SPLIT_FAKE_DEVICES, _SPLIT_STAGE.
+#ifdef MI_LAB
+static inline const char * mi_lab_env(const char * name) { return getenv(name); }
+#else
+static inline const char * mi_lab_env(const char *) { return nullptr; }
+#endif
 // ---- plugin-wide objects (defined in backend.cpp) ----
 struct mi_device_ctx {            // ggml_backend_device::context
     int  device;                  // HIP ordinal
@@ -92,6 +102,7 @@ struct mi_backend_ctx {           // ggml_backend::context  (one HIP stream)
     struct mi_act_cache * act_cache;   // kernels.h
     char         name[32];
     hipEvent_t   copy_ev;         // cross-backend copies: recorded on this stream, waited for by the destination's (created at first use)
+    struct mi_split_events * split_ev;    // split.cpp: join events of row-split MUL_MATs issued through this backend (created at first use)
 };
 struct mi_buffer_ctx {            // ggml_backend_buffer::context
     int    device;
@@ -108,10 +119,12 @@ void * mi_scratch(mi_backend_ctx * ctx, size_t size);       // grow-only scratch
 // row-split weight buffers (split.cpp)
 ggml_backend_buffer_t mi_make_buffer(ggml_backend_buffer_type_t buft, const ggml_backend_buffer_i & iface, void * ctx, size_t size);
 int  mi_device_count();
-ggml_backend_dev_t mi_device(int i);
+ggml_backend_dev_t mi_device(int i);                        // i = index among the kept (gfx950) devices
+int  mi_device_ordinal(int i);                              // its HIP ordinal (-1: no such device)
 bool mi_buft_is_split(ggml_backend_buffer_type_t buft);
 bool mi_tensor_is_split(const ggml_tensor * t);
 bool mi_split_supports_mul_mat(const ggml_tensor * op);
+void mi_split_free_events(mi_backend_ctx * ctx);
 void mi_split_mul_mat(mi_backend_ctx * ctx, const ggml_tensor * dst);          // dst = MUL_MAT(split weight, f32 activations), gathered on ctx's device
 
 // weight re-layout (backend.cpp / kernels_tile.hip / tile_layout.h)

@@ -47,6 +47,11 @@ struct SpecState {
 // prompt: target over all tokens (features for the draft), draft over tokens 1..n-1
 static int spec_prompt(SpecState & s, const int32_t * prompt, int n) {
     const int E = s.tgt->cfg.n_embd;
+    // The device-side hand-offs (chain ids -> the target's GET_ROWS, the target's features / arg-max -> the chain's first step) pass raw
+    // pointers into the other model's compute buffer and rely on ONE stream ordering the two models' graphs.  Models on different
+    // Backend instances (different streams) take the host hand-off instead: drafted tokens and features cross through the host, which
+    // waits for the producing backend first.
+    if (s.dft && s.dft->be != s.tgt->be) s.device_tokens = false;
     s.tgt->kv.clear(); if (s.dft) s.dft->kv.clear();
     Batch & b = s.bt; b.clear();
     for (int i = 0; i < n; ++i) b.add(prompt[i], i, 0, true);

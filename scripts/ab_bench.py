@@ -1,5 +1,6 @@
 """A/B of environment knobs on one box: python scripts/ab_bench.py "KNOB=1" ["KNOB2=1" ...] -- runs bench.py alternately without / with each
 setting (same process order A B A B) and prints tokens/s, ms/round and the mat-vec average."""
+import os; os.environ.setdefault("EH_LAB_PLUGIN", "1")      # lab knobs / stamp kernels live in the --lab build of the plugin only
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 variants = [("base", {})] + [(v, dict([v.split("=", 1)])) for v in sys.argv[1:]]

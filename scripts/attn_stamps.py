@@ -1,5 +1,6 @@
 """In-kernel phase stamps of k_attn_small (diagnostic build): python scripts/attn_stamps.py [T] [n_kv]
 0 entry | 1 V prefetch + q conversion issued | 2 scores written | 3 after barrier | 4 soft-max done | 5 after barrier | 6 V.p done | 7 exit"""
+import os; os.environ.setdefault("EH_LAB_PLUGIN", "1")      # lab knobs / stamp kernels live in the --lab build of the plugin only
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ["GGML_MI355X_ATTN_STAMPS"] = "1"

@@ -1,4 +1,5 @@
 """Which mat-vec kernel serves a (type, T, k) product (GGML_MI355X_DEBUG_MMQ=1)."""
+import os; os.environ.setdefault("EH_LAB_PLUGIN", "1")      # lab knobs / stamp kernels live in the --lab build of the plugin only
 import sys, os
 os.environ["GGML_MI355X_DEBUG_MMQ"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'tests'))

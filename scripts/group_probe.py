@@ -1,4 +1,5 @@
 """Prints the mat-vec grouping decisions of graph_compute for one small decode (GGML_MI355X_DEBUG_GROUP=1)."""
+import os; os.environ.setdefault("EH_LAB_PLUGIN", "1")      # lab knobs / stamp kernels live in the --lab build of the plugin only
 import sys, os
 os.environ["GGML_MI355X_DEBUG_GROUP"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'tests'))

@@ -2,6 +2,7 @@
     python scripts/mmt_stamps.py [T] [rows] [k] [mode]
 Phases (100 MHz s_memrealtime, per wave, lane 0): 0 entry | 1 own share of the activation image quantised | 2 after the prologue barrier |
 3 first row group's units done | 4 after the reduction barrier | 5 first group's epilogue done | 6 kernel exit."""
+import os; os.environ.setdefault("EH_LAB_PLUGIN", "1")      # lab knobs / stamp kernels live in the --lab build of the plugin only
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ["GGML_MI355X_MMT_STAMPS"] = "1"

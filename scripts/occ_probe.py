@@ -1,4 +1,5 @@
 """Prints the occupancy the plugin derives for its mat-vec kernels (GGML_MI355X_DEBUG_OCC=1) on a few shapes."""
+import os; os.environ.setdefault("EH_LAB_PLUGIN", "1")      # lab knobs / stamp kernels live in the --lab build of the plugin only
 import sys, os
 os.environ["GGML_MI355X_DEBUG_OCC"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(ROOT, 'tests'))

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("EH_LAB_PLUGIN", "1")      # lab knobs / stamp kernels live in the --lab build of the plugin only
 import sys, os; sys.path.insert(0,'/root/repo/tests')
 os.environ["GGML_MI355X_TRACE_OPS"]="1"
 from conftest import load_package

@@ -121,6 +121,26 @@ def test_fused_draft_chain_equals_stepwise(ea, gpu, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_draft_on_a_second_backend_instance(ea, gpu):
+    """The chain's device-side hand-offs (drafted ids -> the target's GET_ROWS, the target's features / arg-max -> the chain's first step)
+    are ordered by ONE stream.  With the draft head on a second backend instance (its own stream) the driver must take the host hand-off
+    (host/driver.cpp: spec_prompt gates `device_tokens` on tgt->be == dft->be) and still produce exactly the same tokens and counts."""
+    other = ea.Backend.mi355x(0)                              # a second ggml_backend_t on the same device: a different HIP stream
+    prompt = [int(x) for x in np.random.default_rng(123).integers(5, 512, 24)]
+    res = []
+    for be_d in (gpu, other):
+        t = ea.Model(gpu, "tiny-gqa", "q4_k_m", n_ctx=1024, seed=17)
+        d = ea.Model(be_d, "tiny-gqa", "q4_k_m", n_ctx=1024, eagle_of=t, seed=17, accept_p=0.75)
+        spec, st = ea.spec_generate(t, d, prompt, 300, n_draft=5)
+        res.append((spec, st["n_accept"], st["n_drafted"], st["n_iters"]))
+        plain, _ = ea.plain_generate(t, prompt, 300)
+        assert plain == spec[:len(plain)]
+        d.close(); t.close()
+    assert res[0] == res[1]
+    assert res[0][1] > 20
+
+
+@pytest.mark.gpu
 def test_long_generation_stays_lossless(ea, gpu):
     """1500 generated tokens on the tiny pair: n_kv grows through many 32-cell paddings (attention LDS image sizes, 8- and
     16-token tiles, the fused draft chain's up-front KV slots); speculative output must stay identical to plain greedy decoding."""
