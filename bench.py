@@ -20,7 +20,8 @@ Roofline of the dominant kernel family (quantised mat-vec): algorithmic bytes pe
   * `hip_events`: HIP events around every launch on the plugin's stream in this process (raw pairs and net of an empty pair).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-N > 1 (one process per GPU, launched by torch.distributed.run): see DESIGN.md "multi-GPU".
+N > 1: one process per GPU over RCCL (bench_tp.py).  Under `python -m torch.distributed.run ... bench.py --gpus N` every rank reads RANK /
+WORLD_SIZE from the environment; a bare `python bench.py --gpus N` starts its own N ranks first (spawn_ranks) -- see DESIGN.md "multi-GPU".
 """
 import argparse
 import csv
@@ -166,6 +167,36 @@ def rocprof_roofline(args):
         shutil.rmtree(out, ignore_errors=True)
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks ourselves (one process per GPU through
+    torch.distributed.run, rendezvous on 127.0.0.1 and a free port), BEFORE this process has made any GPU call, relay rank 0's JSON line
+    and exit with the launcher's code.  Under the driver's own `python -m torch.distributed.run ... bench.py --gpus N` WORLD_SIZE is set and
+    this function is not reached.  `--rank-script` (tests/test_bench_launcher.py) substitutes the per-rank program."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    script = os.path.abspath(args.rank_script) if args.rank_script else os.path.abspath(__file__)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("EH_FORCE_TP", None)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line is None:
+        sys.stderr.write(f"bench.py: the {args.gpus} ranks ended (exit {rc}) without a result line\n")
+        return rc or 1
+    res = json.loads(line)
+    res["launcher"] = f"bench.py started {args.gpus} ranks itself (torch.distributed.run, 127.0.0.1:{port})"
+    print(json.dumps(res), flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,10 +209,17 @@ def main():
     ap.add_argument("--no-rocprof", action="store_true", help="skip the rocprofv3 child run (roofline.achieved then comes from HIP events)")
     ap.add_argument("--no-extra", action="store_true", help="skip the accept_p sweep and the tree / Q8_0 workloads")
     ap.add_argument("--rocprof-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--rank-script", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    if args.rocprof_child:
+    if args.rocprof_child or args.pmc_child:
         return rocprof_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        argv = [a for a in sys.argv[1:]]
+        if args.rank_script:                                       # (the substitute gets the same flags minus its own name)
+            i = argv.index("--rank-script"); del argv[i:i + 2]
+        return spawn_ranks(args, argv)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("EH_FORCE_TP"):      # EH_FORCE_TP=1: rehearse the TP path with a 1-rank communicator
         from bench_tp import main_tp           # one process per GPU, row-split tensor parallel over RCCL
@@ -312,4 +350,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

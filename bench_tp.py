@@ -1,11 +1,12 @@
 """bench_tp.py -- the N > 1 leg of bench.py: row-split tensor parallelism, one process per GPU, RCCL over xGMI.
 
+    python bench.py --gpus N ...                       (bench.py starts the N ranks itself when WORLD_SIZE is not set)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Sharding (SURVEY.md 8e / DESIGN.md 6): every rank holds a slice of the SAME global synthetic Vicuna-7B tensors --
 wq/wk/wv/gate/up by output rows (heads), wo/ffn_down by k in whole 256-element super-blocks -- keeps its own heads' KV,
-and the layer needs two all-reduces of [n_embd, T] fp32, enqueued by the host on the plugin's HIP stream between graph
-segments (host/model.cpp cut points, host/tp.cpp).  The EAGLE head and the LM head stay on rank 0: rank 0 drafts, the
+and the layer needs two all-reduces of [n_embd, T] fp32, enqueued on the plugin's HIP stream from INSIDE graph_compute (the plugin's
+node hooks call host/tp.cpp back after wo / ffn_down: a forward is one submission; EH_TP_SEGMENTS=1 restores the segment loop).  The EAGLE head and the LM head stay on rank 0: rank 0 drafts, the
 draft tokens are broadcast (8 ints, gloo), all ranks verify together, rank 0 accepts and broadcasts the count.
 Total work is fixed as N grows => "scaling": "strong".  The same code path runs on CPU with gloo in
 tests/test_tp_gloo.py (world_size 2) and, with EH_FORCE_TP=1, on one GPU with a 1-rank RCCL communicator.
@@ -20,36 +21,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 N_DRAFT = 5
 
 
-def main_tp(args, rank, world, local):
+class GpuRanks:
+    """What a rank needs from its platform: one MI355X per process, the plugin as backend, RCCL for the data path.
+    (tests/bench_rank_cpu.py has the CPU twin -- reference CPU backend + gloo -- with which the launcher and this file's round
+    protocol are rehearsed without a GPU; nothing in this file or in bench.py knows about it.)"""
+    name = "MI355X, RCCL over xGMI"
+    has_profile = True
+
+    def init(self, rank, world, local):
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        return dist.new_group(backend="gloo")               # small host-side control messages (token ids)
+
+    def backend(self, ea, local):
+        return ea.Backend.mi355x(local)
+
+    def bind_allreduce(self, ea, be, model, rank, world, ctl):
+        """RCCL communicator on the plugin's own HIP stream (host/tp.cpp); returns the communicator's size as RCCL reports it."""
+        import torch
+        import torch.distributed as dist
+        h = ea._model_sigs()
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = C.create_string_buffer(128)
+            assert h.eh_tp_unique_id(raw) == 0, "librccl not loadable"
+            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+        dist.broadcast(idbuf, 0, group=ctl)
+        comm = h.eh_tp_init(be.h, bytes(idbuf.numpy().tobytes()), rank, world)
+        assert comm, "ncclCommInitRank failed"
+        h.eh_tp_bind(comm, model.h)
+        return int(h.eh_tp_comm_size(comm))
+
+    def device_sync(self):
+        import torch
+        torch.cuda.synchronize()
+
+
+def main_tp(args, rank, world, local, platform=None):
     import numpy as np
     import torch
     import torch.distributed as dist
     from bench import load_pkg, prompt_tokens, PROMPT_LEN
 
-    torch.cuda.set_device(local)
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    ctl = dist.new_group(backend="gloo")                    # small host-side control messages (token ids)
+    plat = platform or GpuRanks()
+    ctl = plat.init(rank, world, local)
     ea = load_pkg()
     h = ea._model_sigs()
-    be = ea.Backend.mi355x(local)
+    be = plat.backend(ea, local)
+    n_ctx = 2048 if args.config != "tiny-gqa" else 512
 
-    idbuf = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        raw = C.create_string_buffer(128)
-        assert h.eh_tp_unique_id(raw) == 0, "librccl not loadable"
-        idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-    dist.broadcast(idbuf, 0, group=ctl)
-    comm = h.eh_tp_init(be.h, bytes(idbuf.numpy().tobytes()), rank, world)
-    assert comm, "ncclCommInitRank failed"
-
-    tgt = ea.Model(be, args.config, args.ftype, n_ctx=2048, seed=42, tp_rank=rank, tp_size=world)
-    h.eh_tp_bind(comm, tgt.h)
-    dft = ea.Model(be, args.config, args.ftype, n_ctx=2048, eagle_of=tgt, seed=42, accept_p=args.accept_p) if rank == 0 else None
-    prompt = prompt_tokens(1234)
+    tgt = ea.Model(be, args.config, args.ftype, n_ctx=n_ctx, seed=42, tp_rank=rank, tp_size=world)
+    comm_size = plat.bind_allreduce(ea, be, tgt, rank, world, ctl)
+    dft = ea.Model(be, args.config, args.ftype, n_ctx=n_ctx, eagle_of=tgt, seed=42, accept_p=args.accept_p) if rank == 0 else None
+    prompt = prompt_tokens(1234, vocab=tgt.n_vocab if hasattr(tgt, "n_vocab") else 32000)
 
     def sync():
-        torch.cuda.synchronize()
+        plat.device_sync()
         dist.barrier()
 
     # ---- prompt (all ranks decode it; rank 0 also primes the draft) -------------------------------------------------
@@ -110,12 +140,13 @@ def main_tp(args, rank, world, local):
     # collectives, rank 0 brackets its launches with HIP events (plugin profile hooks)
     n_acc, n_dr = st[2], st[1]
     from bench import plugin_lib, HBM_PEAK_GBS
-    prof = plugin_lib(ea)
-    if rank == 0: prof.ggml_backend_mi355x_profile_begin()
-    for _ in range(args.steps):
-        one_round()
+    prof = plugin_lib(ea) if plat.has_profile else None
+    if rank == 0 and prof: prof.ggml_backend_mi355x_profile_begin()
+    if prof:
+        for _ in range(args.steps):
+            one_round()
     roofline = None
-    if rank == 0:
+    if rank == 0 and prof:
         out = (C.c_double * 4)()
         n_launch = prof.ggml_backend_mi355x_profile_end(out)
         raw_ms, alg_bytes, pair_ms = out[0], out[1], out[2]
@@ -133,6 +164,8 @@ def main_tp(args, rank, world, local):
                "config": {"workload": f"{args.config} {args.ftype} target row-split TP={world} (2 RCCL all-reduces/layer) + EAGLE head on rank 0, depth {N_DRAFT}, "
                                       f"{PROMPT_LEN}-token synthetic prompt, greedy", "n_draft": N_DRAFT, "accept_p_synthetic": args.accept_p},
                "accept_rate": round(n_acc / max(1.0, n_dr), 4), "tokens_per_round": round(n_tok / args.steps, 3),
+               "ranks": world, "communicator_size": comm_size, "platform": plat.name,
+               "allreduce_submission": "enqueued from inside graph_compute (plugin node hooks): one submission per forward" if os.environ.get("EH_TP_SEGMENTS") is None and plat.has_profile else "host-issued between graph segments",
                "shard_weight_bytes": tgt.weight_bytes, "allreduces": tgt.n_allreduce, "roofline": roofline,
                "cpu_baseline": None}      # the CPU baseline is timed by the N = 1 run only (bench.py)
         print(json.dumps(res), flush=True)

@@ -60,6 +60,7 @@ def host():
             "eh_backend_load": (vp, [C.c_char_p, C.c_char_p, i32, C.c_char_p, i32]),
             "eh_backend_free": (None, [vp]), "eh_backend_name": (C.c_char_p, [vp]),
             "eh_backend_description": (C.c_char_p, [vp]),
+            "eh_backend_set_node_hooks": (i32, [vp, C.POINTER(vp), i32, vp, vp]), "eh_tensor_data": (vp, [vp]),
             "eh_backend_set_threads": (None, [vp, i32]), "eh_backend_is_host": (i32, [vp]),
             "eh_ctx_new": (vp, [vp, i32]), "eh_ctx_free": (None, [vp]), "eh_ctx_use_split": (i32, [vp, i32, C.POINTER(C.c_float)]),
             "eh_tensor_new": (vp, [vp, i32, i64, i64, i64, i64]),
@@ -110,6 +111,25 @@ class Backend:
     @property
     def description(self):
         return host().eh_backend_description(self.h).decode()
+
+
+_hook_keep = {}
+
+
+def set_node_hooks(backend, tensors, hook):
+    """Plugin node hooks: `hook` (a ctypes CFUNCTYPE(None, c_void_p user, c_void_p tensor, c_void_p stream) object) is called from inside
+    graph_compute after each of `tensors` has been queued; an empty list removes them.  The array is kept alive here."""
+    if not tensors or hook is None:
+        host().eh_backend_set_node_hooks(backend.h, None, 0, None, None); _hook_keep.pop(id(backend), None); return
+    arr = (C.c_void_p * len(tensors))(*tensors)
+    _hook_keep[id(backend)] = (arr, hook)
+    rc = host().eh_backend_set_node_hooks(backend.h, arr, len(tensors), C.cast(hook, C.c_void_p), None)
+    if rc != 0:
+        raise RuntimeError("the backend has no node hooks (ggml_backend_mi355x_set_node_hooks)")
+
+
+def tensor_data(t):
+    return host().eh_tensor_data(t)
 
 
 class Graph:
@@ -284,7 +304,7 @@ def _model_sigs():
     sig = {
         "eh_model_create": (vp, [vp, i32p, f32, f32, C.c_uint64, f32, i32, vp]),
         "eh_model_free": (None, [vp]), "eh_model_set_allreduce": (None, [vp, ALLREDUCE_CB, vp]), "eh_model_n_allreduce": (i64, [vp]),
-        "eh_tp_unique_id": (i32, [C.c_char_p]), "eh_tp_init": (vp, [vp, C.c_char_p, i32, i32]), "eh_tp_bind": (None, [vp, vp]), "eh_tp_free": (None, [vp]), "eh_model_weight_bytes": (i64, [vp]), "eh_model_n_nodes": (i32, [vp]),
+        "eh_tp_unique_id": (i32, [C.c_char_p]), "eh_tp_init": (vp, [vp, C.c_char_p, i32, i32]), "eh_tp_bind": (None, [vp, vp]), "eh_tp_free": (None, [vp]), "eh_tp_comm_size": (i32, [vp]), "eh_model_weight_bytes": (i64, [vp]), "eh_model_n_nodes": (i32, [vp]),
         "eh_model_decode": (i32, [vp, i32, i32p, i32p, i32p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), i32]),
         "eh_model_n_outputs": (i32, [vp]), "eh_model_logits": (C.POINTER(C.c_float), [vp]), "eh_model_hidden": (C.POINTER(C.c_float), [vp]),
         "eh_model_kv_clear": (None, [vp]), "eh_model_kv_seq_rm": (None, [vp, i32, i32, i32]),

@@ -51,6 +51,12 @@ int mi_device_ordinal(int i) { return (i >= 0 && i < g_ndev) ? g_devctx[i].devic
 // it once, in place, into 16-row x 1-unit tiles and tags the tensor through ggml_tensor::extra (which belongs to the backend
 // that owns the buffer, as in the reference: ggml-cuda.cu:840).  Every other way to see the bytes goes through mi_untile() or
 // an on-the-fly inverse, so hosts keep observing ggml's layout: get_tensor, cpy_tensor, partial set_tensor / memset.
+// Threads: raw -> tiled is race-free -- mi_ensure_tiled() takes g_tile_mu, the conversion is synchronous (device drained before, stream
+// drained after) and the tag flips last, so every launch path (all of them call mi_ensure_tiled first) sees either "raw, ineligible
+// for good" or "tiled, conversion complete".  tiled -> raw happens only when a host writes part of the tensor, or a view of it becomes a
+// mat-mul operand: touching a weight while another thread's graph reads it is a race under ggml's contract on any backend.
+// tiled_read() (get_tensor) converts into scratch and leaves the tensor alone.  The scratch (as large as the largest weight converted)
+// is given back at the end of the graph that used it (mi_tile_release_scratch): conversions are first-use events.
 static char g_tag_tiled, g_tag_notile;
 static std::mutex g_tile_mu;
 static void * g_tile_scratch[MI_MAX_DEVICES] = {};
@@ -62,6 +68,11 @@ static void * tile_scratch(int dev, size_t n) {
         HIP_CHECK(hipMalloc(&g_tile_scratch[dev], n)); g_tile_scratch_size[dev] = n;
     }
     return g_tile_scratch[dev];
+}
+void mi_tile_release_scratch(int dev) {
+    if (!g_tile_scratch[dev]) return;                                  // (unlocked peek: the common case, nothing was converted)
+    std::lock_guard<std::mutex> lk(g_tile_mu);
+    if (g_tile_scratch[dev]) { set_device(dev); HIP_CHECK(hipFree(g_tile_scratch[dev])); g_tile_scratch[dev] = nullptr; g_tile_scratch_size[dev] = 0; }
 }
 static inline ggml_tensor * tile_root(const ggml_tensor * t) { return (ggml_tensor *)(t->view_src ? t->view_src : t); }
 bool mi_is_tiled(const ggml_tensor * t) { return t->extra == (void *) &g_tag_tiled; }
@@ -410,7 +421,20 @@ extern "C" GGML_MI355X_API int ggml_backend_mi355x_top_k(ggml_backend_t b, const
     memcpy(ids, s->host, (size_t) n_rows * k * 4); memcpy(vals, s->host + (size_t) n_rows * k * 4, (size_t) n_rows * k * 4);
     return 0;
 }
+// hosts that need a collective between two nodes of a graph (tensor parallel: all-reduce of the partial sums after wo / ffn_down):
+// `fn(user, t, stream)` is called from inside graph_compute when the node that produces nodes[i] has been queued on `stream`; what fn
+// enqueues there (ncclAllReduce in place on t->data) runs before every later node.  The tensors should carry GGML_TENSOR_FLAG_OUTPUT
+// so that no fusion swallows them.  nodes == NULL / n == 0 removes the hooks.  The array must stay valid while they are set.
+extern "C" GGML_MI355X_API int ggml_backend_mi355x_set_node_hooks(ggml_backend_t b, const ggml_tensor * const * nodes, int n,
+                                                                  void (*fn)(void * user, const ggml_tensor * t, void * stream), void * user) {
+    if (!be_is_ours(b)) return -1;
+    mi_backend_ctx * c = (mi_backend_ctx *) b->context;
+    if (!nodes || n <= 0 || !fn) { c->node_hook = nullptr; c->node_hook_user = nullptr; c->hook_nodes = nullptr; c->n_hook_nodes = 0; return 0; }
+    c->node_hook = fn; c->node_hook_user = user; c->hook_nodes = nodes; c->n_hook_nodes = n;
+    return 0;
+}
 static void * reg_proc(ggml_backend_reg_t, const char * name) {
+    if (!strcmp(name, "ggml_backend_mi355x_set_node_hooks")) return (void *) ggml_backend_mi355x_set_node_hooks;
     if (!strcmp(name, "ggml_backend_mi355x_stream"))     return (void *) backend_stream;
     if (!strcmp(name, "ggml_backend_mi355x_top_k"))      return (void *) ggml_backend_mi355x_top_k;
     if (!strcmp(name, "ggml_backend_get_features"))      return (void *) reg_get_features;

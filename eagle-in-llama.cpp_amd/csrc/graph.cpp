@@ -14,6 +14,7 @@
 // launches one kernel (or more) per node.  supports_op mirrors the role of :2946-3229.
 #include "kernels.h"
 #include <vector>
+#include <unordered_set>
 #include <algorithm>
 #include <cmath>
 
@@ -561,9 +562,15 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
     static const bool no_fuse = getenv("GGML_MI355X_NO_FUSION") != nullptr;
     const bool fuse = !no_fuse;
 
+    // node hooks (backend.cpp: ggml_backend_mi355x_set_node_hooks): fired when the loop passes the producing node -- its work (or the
+    // fused launch that swallowed it, earlier) is queued by then
+    std::unordered_set<const ggml_tensor *> hooked;
+    if (ctx->node_hook) for (int j = 0; j < ctx->n_hook_nodes; ++j) hooked.insert(ctx->hook_nodes[j]);
+    auto fire = [&](const ggml_tensor * t) { if (!hooked.empty() && hooked.count(t)) ctx->node_hook(ctx->node_hook_user, t, (void *) st); };
+
     for (int i = 0; i < n; ++i) {
         ggml_tensor * t = g->nodes[i];
-        if (c.done[i] || is_view_op(t->op) || mi_nelements(t) == 0) continue;
+        if (c.done[i] || is_view_op(t->op) || mi_nelements(t) == 0) { if (c.done[i] != 2) fire(t); continue; }
         ggml_tensor * nx = (i + 1 < n) ? g->nodes[i + 1] : nullptr;
         const bool single_use = fuse && c.n_uses(t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
         { static const bool trace = mi_lab_env("GGML_MI355X_TRACE_OPS") != nullptr; if (trace) MI_LOG("node %4d op %2d %-24s [%lld %lld %lld] src0 %s src1 %s", i, (int) t->op, t->name, (long long) t->ne[0], (long long) t->ne[1], (long long) t->ne[2], t->src[0] ? t->src[0]->name : "-", t->src[1] ? t->src[1]->name : "-"); }
@@ -619,8 +626,10 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
                 MI_LOG("graph_compute: op %d (%s) is not supported -- supports_op should have declined it", t->op, t->name);
                 return GGML_STATUS_FAILED;
         }
+        if (c.done[i] != 2) fire(t);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { MI_LOG("graph_compute: launch error: %s", hipGetErrorString(e)); return GGML_STATUS_FAILED; }
+    mi_tile_release_scratch(ctx->device);                             // first-use weight conversions of this graph are done
     return GGML_STATUS_SUCCESS;
 }

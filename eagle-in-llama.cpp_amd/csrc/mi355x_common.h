@@ -102,6 +102,12 @@ struct mi_backend_ctx {           // ggml_backend::context  (one HIP stream)
     struct mi_act_cache * act_cache;   // kernels.h
     char         name[32];
     hipEvent_t   copy_ev;         // cross-backend copies: recorded on this stream, waited for by the destination's (created at first use)
+    // node hooks ("ggml_backend_mi355x_set_node_hooks", include/ggml_mi355x.h): graph_compute calls node_hook(user, t, stream) right after the
+    // work of the node producing one of hook_nodes[] has been queued -- a host enqueues its RCCL all-reduce there, a forward stays ONE submission
+    void       (*node_hook)(void * user, const ggml_tensor * t, void * stream);
+    void *       node_hook_user;
+    const ggml_tensor * const * hook_nodes;
+    int          n_hook_nodes;
     struct mi_split_events * split_ev;    // split.cpp: join events of row-split MUL_MATs issued through this backend (created at first use)
 };
 struct mi_buffer_ctx {            // ggml_backend_buffer::context
@@ -131,6 +137,7 @@ void mi_split_mul_mat(mi_backend_ctx * ctx, const ggml_tensor * dst);          /
 bool mi_is_tiled(const ggml_tensor * t);                    // t itself carries the tiled tag
 bool mi_tile_eligible(const ggml_tensor * w);
 bool mi_ensure_tiled(ggml_tensor * w);                      // first MUL_MAT use: permute in place; returns whether w is tiled now
+void mi_tile_release_scratch(int dev);                      // end of a graph: give the conversion scratch back
 void mi_untile(ggml_tensor * t, bool never_again);         // back to ggml's layout (t or the tensor it views)
 // hipFuncAttributeMaxDynamicSharedMemorySize for `fn` on the CURRENT device, once per (kernel, device): the attribute lives in the
 // device's code object, so a kernel first launched on device 1 (row-split buffers) needs its own call

@@ -61,3 +61,8 @@ EH_API int64_t eh_nbytes(void * t) { return (int64_t) nbytes((ggml_tensor *) t);
 EH_API void eh_shape(void * t, int64_t * ne, int64_t * nb) { ggml_tensor * x = (ggml_tensor *) t; for (int i = 0; i < 4; ++i) { ne[i] = x->ne[i]; nb[i] = (int64_t) x->nb[i]; } }
 EH_API int  eh_type(void * t) { return ((ggml_tensor *) t)->type; }
 EH_API int  eh_n_nodes(void * c) { return (int) ((Ctx *) c)->nodes.size(); }
+// plugin node hooks (include/ggml_mi355x.h: ggml_backend_mi355x_set_node_hooks) for hosts / tests driving the C API from Python
+EH_API int eh_backend_set_node_hooks(void * b, void ** nodes, int n, void (*fn)(void *, const ggml_tensor *, void *), void * user) {
+    return ((mh::Backend *) b)->set_node_hooks((const ggml_tensor * const *) nodes, n, fn, user) ? 0 : -1;
+}
+EH_API void * eh_tensor_data(void * t) { return ((ggml_tensor *) t)->data; }

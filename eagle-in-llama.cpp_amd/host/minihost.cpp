@@ -210,6 +210,12 @@ bool Backend::top_k(const ggml_tensor * logits, const int32_t * rows, int n_rows
     fn_t fn = (fn_t) reg->iface.get_proc_address(reg, name);
     return fn && fn(be, logits, rows, n_rows, k, ids, vals) == 0;
 }
+bool Backend::set_node_hooks(const ggml_tensor * const * nodes, int n, node_hook_fn fn, void * user) {
+    typedef int (*fn_t)(ggml_backend_t, const ggml_tensor * const *, int, node_hook_fn, void *);
+    if (!reg || !reg->iface.get_proc_address) return false;
+    fn_t f = (fn_t) reg->iface.get_proc_address(reg, "ggml_backend_mi355x_set_node_hooks");
+    return f && f(be, nodes, n, fn, user) == 0;
+}
 bool Ctx::use_split(int main_device, const float * tensor_split) {
     if (!be->reg->iface.get_proc_address) return false;
     typedef ggml_backend_buffer_type_t (*fn_t)(int, const float *);

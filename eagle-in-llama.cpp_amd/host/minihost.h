@@ -42,6 +42,10 @@ struct Backend {
     // k best entries of rows of a device tensor through the plugin's "ggml_backend_mi355x_top_k" extension; false when the backend has
     // none (reference CPU backend) or declines the operands -- the caller then reads the rows back
     bool top_k(const ggml_tensor * logits, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals);
+    // "ggml_backend_mi355x_set_node_hooks": fn(user, t, stream) from inside graph_compute after the node producing nodes[i]; false when
+    // the backend has no such extension (reference CPU backend: the caller then computes the graph in segments)
+    typedef void (*node_hook_fn)(void * user, const ggml_tensor * t, void * stream);
+    bool set_node_hooks(const ggml_tensor * const * nodes, int n, node_hook_fn fn, void * user);
     void synchronize();
     bool supports_op(const ggml_tensor * t) const;
     ggml_backend_buffer_t alloc_buffer(size_t size, int usage);

@@ -320,6 +320,10 @@ static void h2f_row(const uint16_t * src, float * dst, int n) {
 }
 
 // ------------------------------------------------------------------ graph of one forward pass (build_llama :1647 / build_eagle :1839)
+void Model::tp_node_hook(void * user, const ggml_tensor * t, void *) {
+    Model * m = (Model *) user;
+    m->allreduce(m->allreduce_user, t->data, mh::nelements(t)); m->n_allreduce++;
+}
 void Model::build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<Cut> * cuts,
                           ggml_tensor *& result_norm, ggml_tensor *& result_output, ggml_tensor *& result_argmax) {
     const int E = cfg.n_embd, H = n_head_local, Hkv = n_head_kv_local, D = cfg.head_dim, n_ctx = cfg.n_ctx;
@@ -364,7 +368,7 @@ void Model::build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<C
         ggml_tensor * kqv = g.mul_mat(v, kq);
         cur = g.cont_2d(g.permute(kqv, 0, 2, 1, 3), (int64_t) D * H, n_tok);
         cur = g.mul_mat(L.wo, cur);                            // TP: partial sum over this rank's heads
-        if (tp && cuts) cuts->push_back({ (int) g.nodes.size(), cur });
+        if (tp && cuts) { cur->flags |= GGML_TENSOR_FLAG_OUTPUT; cuts->push_back({ (int) g.nodes.size(), cur }); }     // (OUTPUT: no fusion may swallow a tensor that is all-reduced in place)
         if (il == cfg.n_layer - 1) {                           // skip unused tokens :1737-1743
             n_tok = io.n_outputs;
             cur = g.get_rows(cur, io.out_ids);
@@ -378,7 +382,7 @@ void Model::build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<C
         ggml_tensor * up = g.mul_mat(L.up, cur);
         cur = g.mul(gate, up);
         cur = g.mul_mat(L.down, cur);                          // TP: partial sum over this rank's slice of n_ff
-        if (tp && cuts) cuts->push_back({ (int) g.nodes.size(), cur });
+        if (tp && cuts) { cur->flags |= GGML_TENSOR_FLAG_OUTPUT; cuts->push_back({ (int) g.nodes.size(), cur }); }
         cur = g.add(cur, ffn_inp);
         snprintf(nm, sizeof nm, "l_out-%d", il); g.set_name(cur, nm);
         inpL = cur;
@@ -529,7 +533,13 @@ int Model::decode(const Batch & b, bool want_hidden) {
     // ---- compute, then the outputs by asynchronous copies into page-locked memory, one wait for everything
     enum ggml_status st = GGML_STATUS_SUCCESS;
     if (!P.tp) st = g.compute_async();
-    else {
+    else if (tp_in_graph && !P.cuts.empty() && [&] { P.hook_nodes.clear(); for (auto & c : P.cuts) P.hook_nodes.push_back(c.t);
+                                                    return be->set_node_hooks(P.hook_nodes.data(), (int) P.hook_nodes.size(), tp_node_hook, this); }()) {
+        // the plugin calls back from inside graph_compute after every cut tensor: the all-reduces are enqueued on its stream between
+        // the launches, the whole forward is ONE submission (EH_TP_SEGMENTS=1: the segment loop below)
+        st = g.compute_async();
+        be->set_node_hooks(nullptr, 0, nullptr, nullptr);
+    } else {
         int n0 = 0;
         for (auto & c : P.cuts) {
             st = g.compute_range(n0, c.node_end); if (st != GGML_STATUS_SUCCESS) break;

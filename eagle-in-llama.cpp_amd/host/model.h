@@ -79,6 +79,8 @@ struct Model {
     allreduce_fn allreduce = nullptr; void * allreduce_user = nullptr;
     int n_head_local = 0, n_head_kv_local = 0, n_ff_local = 0;
     int64_t n_allreduce = 0;
+    bool tp_in_graph = getenv("EH_TP_SEGMENTS") == nullptr;   // all-reduces enqueued from inside graph_compute (plugin node hooks) when the backend offers them
+    static void tp_node_hook(void * user, const ggml_tensor * t, void * stream);
     size_t weight_bytes = 0;          // bytes of all mat-mul weights resident on the device (for the roofline)
 
     // outputs of the last decode
@@ -115,6 +117,7 @@ struct Model {
     struct Pending {
         bool valid = false; Batch shape; int T = 0, n_kv = 0; bool tp = false, head_here = true, packed = false, want_logits = true; size_t span = 0;
         std::vector<Cut> cuts; KVCache kv_saved;
+        std::vector<const ggml_tensor *> hook_nodes;          // the cut tensors, as handed to the plugin's node hooks
         ggml_tensor * inp_embd = nullptr, * inp_hidd = nullptr, * inp_pos = nullptr, * kq_mask = nullptr, * inp_out = nullptr;
         ggml_tensor * base = nullptr;      // first input tensor: origin of the packed host image
         bool dev_tokens = false;           // the embeddings are fetched on the device (dev_ids below): no inp_embd

@@ -18,20 +18,21 @@ typedef int (*ncclCommInitRank_t)(ncclComm_t *, int, ncclUniqueId, int);
 typedef int (*ncclAllReduce_t)(const void *, void *, size_t, int /*dtype*/, int /*op*/, ncclComm_t, void * /*stream*/);
 typedef int (*ncclBroadcast_t)(const void *, void *, size_t, int, int, ncclComm_t, void *);
 typedef int (*ncclCommDestroy_t)(ncclComm_t);
+typedef int (*ncclCommCount_t)(const ncclComm_t, int *);
 typedef const char * (*ncclGetErrorString_t)(int);
 enum { ncclFloat32 = 7, ncclInt32 = 2, ncclSum = 0 };
 
 struct Rccl {
     void * dl = nullptr;
     ncclGetUniqueId_t get_id = nullptr; ncclCommInitRank_t init_rank = nullptr; ncclAllReduce_t all_reduce = nullptr;
-    ncclBroadcast_t bcast = nullptr; ncclCommDestroy_t destroy = nullptr; ncclGetErrorString_t errstr = nullptr;
+    ncclBroadcast_t bcast = nullptr; ncclCommDestroy_t destroy = nullptr; ncclGetErrorString_t errstr = nullptr; ncclCommCount_t count = nullptr;
     bool load() {
         if (dl) return true;
         for (const char * n : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" }) { dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (dl) break; }
         if (!dl) return false;
         get_id = (ncclGetUniqueId_t) dlsym(dl, "ncclGetUniqueId"); init_rank = (ncclCommInitRank_t) dlsym(dl, "ncclCommInitRank");
         all_reduce = (ncclAllReduce_t) dlsym(dl, "ncclAllReduce"); bcast = (ncclBroadcast_t) dlsym(dl, "ncclBroadcast");
-        destroy = (ncclCommDestroy_t) dlsym(dl, "ncclCommDestroy"); errstr = (ncclGetErrorString_t) dlsym(dl, "ncclGetErrorString");
+        destroy = (ncclCommDestroy_t) dlsym(dl, "ncclCommDestroy"); count = (ncclCommCount_t) dlsym(dl, "ncclCommCount"); errstr = (ncclGetErrorString_t) dlsym(dl, "ncclGetErrorString");
         return get_id && init_rank && all_reduce;
     }
 } g_rccl;
@@ -64,4 +65,6 @@ EH_API void * eh_tp_init(void * backend, const char * id128, int rank, int size)
     return c;
 }
 EH_API void eh_tp_bind(void * comm, void * model) { eh::Model * m = (eh::Model *) model; m->allreduce = rccl_allreduce; m->allreduce_user = comm; }
+// ranks in the communicator as RCCL itself reports them (bench.py prints it next to the number of processes it started)
+EH_API int eh_tp_comm_size(void * comm) { TpComm * c = (TpComm *) comm; int n = 0; if (!c || !c->comm || !g_rccl.count || g_rccl.count(c->comm, &n) != 0) return -1; return n; }
 EH_API void eh_tp_free(void * comm) { TpComm * c = (TpComm *) comm; if (c) { if (c->comm && g_rccl.destroy) g_rccl.destroy(c->comm); delete c; } }

@@ -24,6 +24,7 @@
  *   "ggml_backend_get_features"       (R/src/llama.cpp:12044)                    -> feature list
  * and one extension of ours, "ggml_backend_mi355x_stream": void * (*)(ggml_backend_t) -> the hipStream_t of a backend
  * instance, for hosts that enqueue RCCL collectives between graph segments (tensor parallel, host/tp.cpp);
+ * "ggml_backend_mi355x_set_node_hooks" (below) so that those collectives are enqueued from inside graph_compute,
  * and "ggml_backend_mi355x_top_k" (below) for hosts that draft token trees.
  */
 #ifndef GGML_MI355X_H
@@ -57,6 +58,15 @@ GGML_MI355X_API ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type
  * ids / vals: HOST arrays [n_rows][k] (fewer than k entries in a row: id -1, value -inf).  Ordered behind everything already submitted to
  * `backend`, returns when the results are on the host.  0 = ok, -1 = not supported for these operands (the caller keeps its host path). */
 GGML_MI355X_API int ggml_backend_mi355x_top_k(ggml_backend_t backend, const struct ggml_tensor * logits, const int32_t * rows, int n_rows, int k, int32_t * ids, float * vals);
+
+/* Extension "ggml_backend_mi355x_set_node_hooks": collectives from INSIDE graph_compute.  `fn(user, t, stream)` is called when the node that
+ * produces nodes[i] has been queued on the backend's HIP stream; whatever fn enqueues on `stream` (ncclAllReduce in place on t->data)
+ * is ordered before every later node of the graph, so a tensor-parallel forward is one graph_compute instead of one per all-reduce
+ * (host/tp.cpp, host/model.cpp).  The reference has no counterpart: its -sm row gathers by peer copies inside ggml_cuda_op_mul_mat
+ * (R/ggml/src/ggml-cuda/ggml-cuda.cu:1590-1666).  Mark the tensors GGML_TENSOR_FLAG_OUTPUT so that no fusion swallows them;
+ * nodes == NULL removes the hooks; the array must outlive them.  Returns 0, or -1 for a backend of another plugin. */
+GGML_MI355X_API int ggml_backend_mi355x_set_node_hooks(ggml_backend_t backend, const struct ggml_tensor * const * nodes, int n,
+                                                       void (*fn)(void * user, const struct ggml_tensor * t, void * stream), void * user);
 
 /* measurement hook (not part of the reference's interface): HIP-event timing of every quantised mat-vec launch
  * between begin/end, on the stream the kernels are launched on.  out[0] = kernel milliseconds, out[1] = algorithmic

@@ -318,3 +318,40 @@ def test_attention_long_context(ea, gpu, n_kv, T):
     g.alloc(); g.set(tq, q); g.set(tk, kc); g.set(tv, vc); g.set(tm, mask); g.compute()
     got = g.get(res).reshape(T, H, d)
     assert rel(got, orc.attention(q, kc, vc, mask, float(scale), Hkv)) < 1e-3
+
+
+@pytest.mark.gpu
+def test_node_hooks_fire_in_graph_order_on_the_stream(ea, gpu):
+    """ggml_backend_mi355x_set_node_hooks: the callback runs inside graph_compute right after the hooked node has been queued, and what it
+    enqueues on the stream it is handed is ordered before every later node.  Here the hook zeroes the hooked tensor (hipMemsetAsync on
+    that stream): the nodes behind it must see zeros, the nodes before it must not."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]; hip.hipMemsetAsync.restype = C.c_int
+    rng = np.random.default_rng(5)
+    g = ea.Graph(gpu)
+    a = g.tensor(ea.F32, 256, 4); b = g.tensor(ea.F32, 256, 4)
+    s1 = g.add(a, b)                      # hooked: zeroed by the callback after it was computed
+    s2 = g.add(s1, b)                     # must be 0 + b
+    s3 = g.add(s2, a)                     # hooked as well (left alone): order of the calls
+    s4 = g.add(s3, b)
+    g.alloc()
+    xa = rng.standard_normal((4, 256)).astype(np.float32); xb = rng.standard_normal((4, 256)).astype(np.float32)
+    g.set(a, xa); g.set(b, xb)
+    calls = []
+    HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
+
+    def cb(user, t, stream):
+        calls.append(t)
+        if t == s1:
+            assert hip.hipMemsetAsync(ea.tensor_data(s1), 0, 4 * 256 * 4, stream) == 0
+    hook = HOOK(cb)
+    ea.set_node_hooks(gpu, [s1, s3], hook)
+    g.compute()
+    ea.set_node_hooks(gpu, [], None)
+    assert len(calls) == 2 and calls[0] != calls[1]
+    assert np.array_equal(g.get(s1).reshape(4, 256), np.zeros((4, 256), np.float32))
+    np.testing.assert_allclose(g.get(s2).reshape(4, 256), xb, rtol=0, atol=0)
+    np.testing.assert_allclose(g.get(s4).reshape(4, 256), (xb + xa) + xb, rtol=1e-6)
+    g.compute()                            # hooks removed: the plain result again
+    np.testing.assert_allclose(g.get(s2).reshape(4, 256), (xa + xb) + xb, rtol=1e-6)
