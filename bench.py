@@ -41,7 +41,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N_DRAFT = 5
 PROMPT_LEN = 128
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy)
-MATVEC_KERNELS = ("k_mmt<", "k_mmt2<", "k_mmt_bb<", "k_mmq<", "k_mmvq<")
+INT8_PEAK_TOPS = 5000.0        # MI355X_MICROARCH.md, matrix cores: I8 runs at 2x the BF16 rate (~2.5 PF dense)
+MATVEC_KERNELS = ("k_mmt<", "k_mmt2<", "k_mmt_bb<", "k_bb<", "k_mmq<", "k_mmvq<")
 
 
 def load_pkg():
@@ -71,16 +72,43 @@ def plugin_lib(ea):
     return lib
 
 
-def pmc_traffic():
-    """HBM bytes per mat-vec launch from the committed rocprofv3 --pmc FETCH_SIZE pass of this same command
-    (profiles/r02_pmc_traffic.json, scripts/pmc_summary.py; counters cannot be read from inside the run) -- labelled as such."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["hbm_bytes_per_launch"], name
-        except Exception:
-            continue
-    return None, None
+def pmc_traffic(args):
+    """HBM bytes per mat-vec launch, measured in THIS run: a second rocprofv3 child (`--pmc FETCH_SIZE`, counters in a pass of their own as
+    MI355X_MICROARCH.md prescribes) runs the same speculative rounds between the plugin's marker kernels; FETCH_SIZE is in KiB and on
+    gfx950 tallies the 128-byte requests of wide streaming reads at 64 bytes, hence x 1024 x 2.  Writes (T x rows x 4 bytes per launch) are
+    not counted: WRITE_SIZE does not fit the same pass and is < 0.1 % of the traffic here."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    steps = max(2, min(args.steps, 10))
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__), "--pmc-child",
+           "--steps", str(steps), "--warmup", "1", "--config", args.config, "--ftype", args.ftype, "--accept-p", str(args.accept_p)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+        files = glob.glob(out + "/**/*counter_collection.csv", recursive=True)
+        if not files:
+            return None, "no counter file: " + (r.stderr or r.stdout)[-200:]
+        rows = [x for x in csv.DictReader(open(files[0])) if x.get("Counter_Name") == "FETCH_SIZE" or "k_profile_mark" in x.get("Kernel_Name", "")]
+        rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+        marks = [i for i, x in enumerate(rows) if "k_profile_mark" in x["Kernel_Name"]]
+        if len(marks) < 2:
+            return None, "marker kernels not found in the counter file"
+        sel = [x for x in rows[marks[-2] + 1:marks[-1]] if x.get("Counter_Name") == "FETCH_SIZE" and any(k in x["Kernel_Name"] for k in MATVEC_KERNELS)]
+        if not sel:
+            return None, "no mat-vec dispatches between the markers"
+        kib = sum(float(x["Counter_Value"]) for x in sel)
+        keep = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(keep):
+            try:
+                shutil.copy(files[0], os.path.join(keep, "bench_pmc_counter_collection.csv"))
+            except Exception:
+                pass
+        return round(kib * 1024 * 2 / len(sel)), f"rocprofv3 --pmc FETCH_SIZE child of this run: {len(sel)} mat-vec launches of {steps} rounds, KiB x 1024 x 2 (gfx950 correction)"
+    except Exception as e:
+        return None, str(e)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def cpu_baseline(ea, cfg, ftype, rounds=10):
@@ -227,6 +255,7 @@ def main():
 
     # the rocprofv3 pass first, while this process has not touched the GPU yet: it is a child process of its own
     rp = None if args.no_rocprof else rocprof_roofline(args)
+    pmc = (None, "skipped (--no-rocprof)") if args.no_rocprof else pmc_traffic(args)
 
     import torch                                # plumbing only: barrier-free at N=1, used for cuda.synchronize()
     ea = load_pkg()
@@ -276,9 +305,8 @@ def main():
         achieved = bpl / (avg_us * 1e-6) / 1e9 if n_launch else 0.0
         src = "HIP events net of an empty event pair (rocprofv3 child run unavailable: %s)" % (rp or {}).get("error", "skipped")
         extra_rp = None
-    traffic, traffic_src = pmc_traffic()
     roofline = {"bound": "hbm", "kernel": "quantised mat-vec family: k_mmt (tiled weights, int8 MFMA, in-kernel Q8_K quantiser; 1..8 tokens)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": f"profiles/{traffic_src} (committed PMC pass, not this run)" if traffic_src else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc[0], "traffic_source": pmc[1],
                 "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": round(bpl), "source": src, "rocprof": extra_rp, "hip_events": ev}
 
     res = {"metric": "accepted tokens/sec + accept-rate, Vicuna-7B Q4_K_M + EAGLE, 1/8 GPU", "value": round(value, 2), "unit": "tokens/s",
@@ -308,15 +336,17 @@ def main():
         extra["accept_p_sweep"] = sweep
         # the reference's TREE driver (host/tree_driver.cpp): 4 branches forking on p_split, greedy verification
         try:
-            # (the synthetic draft's best logit stands ~55 above the rest: a second candidate passes p_split only at a draft temperature of ~20)
-            ts = ea.TreeSession(tgt, dft, prompt, n_seq_dft=4, n_draft=8, p_split=0.02, temp=0.0, temp_dft=20.0, top_k=8)
+            # (the synthetic draft's best logit stands ~55 above the rest: a second candidate passes p_split only once the draft distribution
+            #  is flattened -- temperature 13 gives a few forks per round without throwing the chain's acceptance away)
+            ts = ea.TreeSession(tgt, dft, prompt, n_seq_dft=4, n_draft=7, p_split=0.02, temp=0.0, temp_dft=13.0, top_k=8)
             ts.run(8)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             tt, tst = ts.run(96)
             torch.cuda.synchronize(); d1 = time.perf_counter() - t1
             ts.close()
-            extra["tree_driver"] = {"workload": "np 4, draft-max 8, p_split 0.02, draft temperature 20 (the synthetic draft is near one-hot: it forks only when flattened), top-k on the device, greedy verification", "tokens_per_s": round(len(tt) / d1, 1),
-                                    "tokens_per_round": round(tst["n_predict"] / max(1.0, tst["n_iters"]), 3), "forks": int(tst["n_forks"]), "max_verify_batch": int(tst["max_batch"])}
+            extra["tree_driver"] = {"workload": "np 4, draft-max 7, p_split 0.02, draft temperature 13 (the synthetic draft is near one-hot: it forks only when flattened), top-k on the device, greedy verification", "tokens_per_s": round(len(tt) / d1, 1),
+                                    "tokens_per_round": round(tst["n_predict"] / max(1.0, tst["n_iters"]), 3), "forks": int(tst["n_forks"]), "max_verify_batch": int(tst["max_batch"]),
+                                    "verify_ms_per_round": round(tst["t_verify_us"] / max(1.0, tst["n_iters"]) / 1e3, 3), "draft_ms_per_round": round(tst["t_draft_us"] / max(1.0, tst["n_iters"]) / 1e3, 3)}
         except Exception as e:
             extra["tree_driver"] = {"error": str(e)}
         res["extra"] = extra
@@ -327,16 +357,36 @@ def main():
         try:
             t8 = ea.Model(be, args.config, "q8_0", n_ctx=2048, seed=42)
             d8 = ea.Model(be, args.config, "q8_0", n_ctx=2048, eagle_of=t8, seed=42, accept_p=args.accept_p)
+            ea.plain_generate(t8, prompt, 8)
+            _, p8 = ea.plain_generate(t8, prompt, 64)                       # the 1x of this configuration: plain greedy decode of the same Q8_0 target
+            plain8 = (p8["n_predict"] - 1) / p8["t_decode_us"] * 1e6
             ts = ea.TreeSession(t8, d8, prompt, n_seq_dft=10, n_draft=60, p_split=0.01, temp=0.0, temp_dft=20.0, top_k=12)
             ts.run(8)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             tt, tst = ts.run(64)
             torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+            # roofline of the verification GEMM (k_bb, >= 25 tokens): HIP events around every launch of 64 more tokens, split by batch size
+            lib.ggml_backend_mi355x_profile_end_by_batch.restype = C.c_int
+            lib.ggml_backend_mi355x_profile_end_by_batch.argtypes = [C.c_int, C.POINTER(C.c_double)]
+            lib.ggml_backend_mi355x_profile_begin()
+            _, tst2 = ts.run(64)
+            o9 = (C.c_double * 9)()
+            lib.ggml_backend_mi355x_profile_end_by_batch(25, o9)
             ts.close()
+            big_ms, big_bytes, big_ops, big_n, pair = o9[4], o9[5], o9[6], o9[7], o9[8]
+            net_ms = max(big_ms - pair * big_n, 1e-9)
+            rf3 = None
+            if big_n > 0:
+                gbs = big_bytes / (net_ms * 1e-3) / 1e9; tops = big_ops / (net_ms * 1e-3) / 1e12
+                rf3 = {"bound": "hbm", "kernel": "k_bb: int8 GEMM on 32x32x32 MFMA tiles, verification batches of >= 25 tokens (HIP events net of an empty pair)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "launches": int(big_n), "avg_launch_us": round(net_ms * 1e3 / big_n, 2),
+                       "algorithmic_bytes_per_launch": round(big_bytes / big_n), "int8_tops": round(tops, 1), "int8_peak_tops": INT8_PEAK_TOPS, "mfma_frac": round(tops / INT8_PEAK_TOPS, 4),
+                       "gemm_ms_per_round": round(net_ms / max(1.0, tst2["n_iters"]), 3)}
             res["extra"]["config3_q8_0_tree"] = {"workload": "vicuna-7b q8_0 + EAGLE head, np 10, draft-max 60 (BASELINE configs[2]: width 10, depth 6), draft temperature 20 so that the tree forks", "forks": int(tst["n_forks"]), "draft_decodes_per_round": round(tst["n_draft_calls"] / max(1.0, tst["n_iters"]), 2), "tokens_per_s": round(len(tt) / d1, 1),
+                                                 "plain_q8_0_tokens_per_s": round(plain8, 1), "speedup_vs_plain_q8_0": round(len(tt) / d1 / plain8, 3),
                                                  "tokens_per_round": round(tst["n_predict"] / max(1.0, tst["n_iters"]), 3), "max_verify_batch": int(tst["max_batch"]),
                                                  "verify_ms_per_round": round(tst["t_verify_us"] / max(1.0, tst["n_iters"]) / 1e3, 3), "draft_ms_per_round": round(tst["t_draft_us"] / max(1.0, tst["n_iters"]) / 1e3, 3),
-                                                 "target_weight_bytes": t8.weight_bytes}
+                                                 "target_weight_bytes": t8.weight_bytes, "roofline": rf3}
             d8.close(); t8.close()
         except Exception as e:
             res["extra"]["config3_q8_0_tree"] = {"error": str(e)}

@@ -483,7 +483,7 @@ static int occupancy_blocks(const void * fn, int threads, size_t lds) {
 }
 static void ensure_lds_attr(const void * fn, size_t bytes) { if (bytes > 48*1024) mi_allow_big_lds(fn); }
 // ---- optional HIP-event profile of every mat-vec launch (bench.py roofline; off by default, zero cost when off)
-struct prof_rec { hipEvent_t a, b; double bytes; };
+struct prof_rec { hipEvent_t a, b; double bytes; int T; double ops; };          // ops: int8 multiply-adds x 2 of the launch (2 T rows k)
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 // count-only mode (no events between the kernels: the launch sequence is the product's): launches and algorithmic bytes between
@@ -526,6 +526,26 @@ extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_profil
     if (out) { out[0] = ms; out[1] = bytes; out[2] = cal.empty() ? 0.0 : cal[cal.size()/2]; out[3] = (double) cal.size(); }
     return n;
 }
+// same as profile_end, the launches split by batch size: out[0..3] = {ms, bytes, int8 ops, launches} of the launches with fewer than
+// min_tokens tokens, out[4..7] of the others (the big-batch GEMM when min_tokens = 25), out[8] = the empty event pair's ms
+extern "C" __attribute__((visibility("default"))) int ggml_backend_mi355x_profile_end_by_batch(int min_tokens, double * out) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    double acc[8] = {};
+    for (auto & r : g_prof) {
+        float t = 0; const int o = r.T >= min_tokens ? 4 : 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { acc[o] += t; acc[o + 1] += r.bytes; acc[o + 2] += r.ops; acc[o + 3] += 1; }
+        (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b);
+    }
+    const int n = (int) g_prof.size();
+    g_prof.clear();
+    std::vector<float> cal;
+    for (auto & r : g_prof_cal) { float t = 0; if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) cal.push_back(t); (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
+    g_prof_cal.clear();
+    std::sort(cal.begin(), cal.end());
+    if (out) { for (int i = 0; i < 8; ++i) out[i] = acc[i]; out[8] = cal.empty() ? 0.0 : cal[cal.size()/2]; }
+    return n;
+}
 // algorithmic bytes of one launch: weights once + fp32 activations once + outputs once
 double mi_launch_bytes(const mmvq_launch & L, int T, bool dual) {
     double b = (double) T * L.k * 4;
@@ -544,9 +564,10 @@ int mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual) {
     if (!g_prof_on) return -1;
     {   // every 64th launch: one empty pair right before, same stream, same queue state
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (g_prof.size() % 64 == 0) { prof_rec c; HIP_CHECK(hipEventCreate(&c.a)); HIP_CHECK(hipEventCreate(&c.b)); c.bytes = 0; HIP_CHECK(hipEventRecord(c.a, st)); HIP_CHECK(hipEventRecord(c.b, st)); g_prof_cal.push_back(c); }
+        if (g_prof.size() % 64 == 0) { prof_rec c; HIP_CHECK(hipEventCreate(&c.a)); HIP_CHECK(hipEventCreate(&c.b)); c.bytes = 0; c.T = 0; c.ops = 0; HIP_CHECK(hipEventRecord(c.a, st)); HIP_CHECK(hipEventRecord(c.b, st)); g_prof_cal.push_back(c); }
     }
     prof_rec r; HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b)); r.bytes = mi_launch_bytes(L, T, dual);
+    r.T = T; r.ops = 0; { const int nm = dual ? 2 : L.n_mat; for (int i = 0; i < nm; ++i) r.ops += 2.0 * T * (double) L.m[i].rows * L.k; }
     HIP_CHECK(hipEventRecord(r.a, st));
     std::lock_guard<std::mutex> lk(g_prof_mu); g_prof.push_back(r);
     return (int) g_prof.size() - 1;

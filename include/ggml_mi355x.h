@@ -73,6 +73,10 @@ GGML_MI355X_API int ggml_backend_mi355x_set_node_hooks(ggml_backend_t backend, c
  * bytes (weights + fp32 activations + outputs); returns the number of launches.  Used by bench.py. */
 GGML_MI355X_API void ggml_backend_mi355x_profile_begin(void);
 GGML_MI355X_API int  ggml_backend_mi355x_profile_end(double * out);
+/* profile_end with the launches split by batch size: out[0..3] = {kernel ms, algorithmic bytes, int8 ops (2 T rows k), launches} of the
+ * launches with fewer than min_tokens tokens, out[4..7] the same of the others, out[8] = ms of an empty event pair.  bench.py prices the
+ * big-batch GEMM of a tree verification with it (min_tokens = 25). */
+GGML_MI355X_API int  ggml_backend_mi355x_profile_end_by_batch(int min_tokens, double * out);
 /* count-only variant for runs under rocprofv3: no events are inserted (the launch sequence is the product's); between begin and end the
  * plugin counts quantised mat-vec launches and their algorithmic bytes, and both calls launch the marker kernel `k_profile_mark`, so the
  * kernel trace of the same process can be cut at exactly these points (bench.py --rocprof-child). */
