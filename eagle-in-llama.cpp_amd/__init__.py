@@ -61,6 +61,8 @@ def host():
             "eh_backend_free": (None, [vp]), "eh_backend_name": (C.c_char_p, [vp]),
             "eh_backend_description": (C.c_char_p, [vp]),
             "eh_backend_set_node_hooks": (i32, [vp, C.POINTER(vp), i32, vp, vp]), "eh_tensor_data": (vp, [vp]),
+            "eh_tensor_info": (None, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
+            "eh_tensor_src": (vp, [vp, i32]), "eh_tensor_view_src": (vp, [vp]),
             "eh_backend_set_threads": (None, [vp, i32]), "eh_backend_is_host": (i32, [vp]),
             "eh_ctx_new": (vp, [vp, i32]), "eh_ctx_free": (None, [vp]), "eh_ctx_use_split": (i32, [vp, i32, C.POINTER(C.c_float)]),
             "eh_tensor_new": (vp, [vp, i32, i64, i64, i64, i64]),
@@ -130,6 +132,17 @@ def set_node_hooks(backend, tensors, hook):
 
 def tensor_data(t):
     return host().eh_tensor_data(t)
+
+
+def tensor_info(t):
+    """dict(ne, nb, type, op, flags, name) of a tensor handle"""
+    ne = (C.c_int64 * 4)(); nb = (C.c_int64 * 4)(); ty = C.c_int(); op = C.c_int(); fl = C.c_int(); nm = C.create_string_buffer(64)
+    host().eh_tensor_info(t, ne, nb, C.byref(ty), C.byref(op), C.byref(fl), nm, 64)
+    return {"ne": list(ne), "nb": list(nb), "type": ty.value, "op": op.value, "flags": fl.value, "name": nm.value.decode()}
+
+
+def tensor_src(t, s):
+    return host().eh_tensor_src(t, s)
 
 
 class Graph:
@@ -304,7 +317,7 @@ def _model_sigs():
     sig = {
         "eh_model_create": (vp, [vp, i32p, f32, f32, C.c_uint64, f32, i32, vp]),
         "eh_model_free": (None, [vp]), "eh_model_set_allreduce": (None, [vp, ALLREDUCE_CB, vp]), "eh_model_n_allreduce": (i64, [vp]),
-        "eh_tp_unique_id": (i32, [C.c_char_p]), "eh_tp_init": (vp, [vp, C.c_char_p, i32, i32]), "eh_tp_bind": (None, [vp, vp]), "eh_tp_free": (None, [vp]), "eh_tp_comm_size": (i32, [vp]), "eh_model_weight_bytes": (i64, [vp]), "eh_model_n_nodes": (i32, [vp]),
+        "eh_tp_unique_id": (i32, [C.c_char_p]), "eh_tp_init": (vp, [vp, C.c_char_p, i32, i32]), "eh_tp_bind": (None, [vp, vp]), "eh_tp_free": (None, [vp]), "eh_tp_comm_size": (i32, [vp]), "eh_model_weight_bytes": (i64, [vp]), "eh_model_n_nodes": (i32, [vp]), "eh_model_node": (vp, [vp, i32]), "eh_model_force_layer_inputs": (None, [vp, C.POINTER(vp), i32]), "eh_model_tensor_read": (None, [vp, vp, vp, i64]),
         "eh_model_decode": (i32, [vp, i32, i32p, i32p, i32p, C.POINTER(C.c_uint8), C.POINTER(C.c_float), i32]),
         "eh_model_n_outputs": (i32, [vp]), "eh_model_logits": (C.POINTER(C.c_float), [vp]), "eh_model_hidden": (C.POINTER(C.c_float), [vp]),
         "eh_model_kv_clear": (None, [vp]), "eh_model_kv_seq_rm": (None, [vp, i32, i32, i32]),
@@ -350,6 +363,34 @@ class Model:
         """fn(ptr:int, n_floats:int) sums the fp32 buffer at `ptr` over all ranks in place (CPU/gloo tests)."""
         self._ar = ALLREDUCE_CB(lambda user, data, n: fn(data, n))
         _model_sigs().eh_model_set_allreduce(self.h, self._ar, None)
+
+    def force_layer_inputs(self, rows):
+        """Teacher forcing for the NEXT decode: rows[il] ([T, n_embd] float32, or None) replaces the input of layer il >= 1."""
+        self._forced = [None if r is None else np.ascontiguousarray(r, np.float32) for r in rows]
+        arr = (C.c_void_p * len(rows))(*[None if r is None else r.ctypes.data for r in self._forced])
+        _model_sigs().eh_model_force_layer_inputs(self.h, arr, len(rows))
+
+    def named_nodes(self, prefix):
+        """{name: values} of the last decode's contiguous f32 nodes whose names start with `prefix`"""
+        out = {}
+        for t in self.nodes():
+            info = tensor_info(t)
+            if info["name"].startswith(prefix) and info["type"] == 0:
+                out[info["name"]] = self.read_tensor(t).reshape(-1, info["ne"][0])
+        return out
+
+    def nodes(self):
+        """handles of the last decode's graph nodes, in execution order (parity tooling)"""
+        h = _model_sigs()
+        return [h.eh_model_node(self.h, i) for i in range(h.eh_model_n_nodes(self.h))]
+
+    def read_tensor(self, t, dtype=np.float32):
+        """contents of a (contiguous) tensor of the last decode's graph, or of a weight, as stored by the backend"""
+        info = tensor_info(t)
+        n = info["nb"][3] * info["ne"][3]
+        out = np.empty(n // np.dtype(dtype).itemsize, dtype=dtype)
+        _model_sigs().eh_model_tensor_read(self.h, t, out.ctypes.data_as(C.c_void_p), n)
+        return out
 
     @property
     def n_allreduce(self):

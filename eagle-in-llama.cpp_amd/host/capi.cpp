@@ -66,3 +66,13 @@ EH_API int eh_backend_set_node_hooks(void * b, void ** nodes, int n, void (*fn)(
     return ((mh::Backend *) b)->set_node_hooks((const ggml_tensor * const *) nodes, n, fn, user) ? 0 : -1;
 }
 EH_API void * eh_tensor_data(void * t) { return ((ggml_tensor *) t)->data; }
+
+// shape / type / op / name / sources of a tensor handle
+EH_API void eh_tensor_info(void * tp, int64_t * ne4, int64_t * nb4, int * type, int * op, int * flags, char * name, int cap) {
+    const ggml_tensor * t = (const ggml_tensor *) tp;
+    for (int i = 0; i < 4; ++i) { ne4[i] = t->ne[i]; nb4[i] = (int64_t) t->nb[i]; }
+    *type = (int) t->type; *op = (int) t->op; *flags = t->flags;
+    if (name && cap > 0) { strncpy(name, t->name, (size_t) cap - 1); name[cap - 1] = 0; }
+}
+EH_API void * eh_tensor_src(void * tp, int s) { return (s >= 0 && s < GGML_MAX_SRC) ? ((ggml_tensor *) tp)->src[s] : nullptr; }
+EH_API void * eh_tensor_view_src(void * tp) { return ((ggml_tensor *) tp)->view_src; }

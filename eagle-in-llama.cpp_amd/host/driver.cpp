@@ -210,6 +210,12 @@ EH_API void eh_model_set_allreduce(void * m, Model::allreduce_fn fn, void * user
 EH_API int64_t eh_model_n_allreduce(void * m) { return ((Model *) m)->n_allreduce; }
 EH_API int64_t eh_model_weight_bytes(void * m) { return (int64_t) ((Model *) m)->weight_bytes; }
 EH_API int eh_model_n_nodes(void * m) { return ((Model *) m)->last_n_nodes; }
+// inspection of the LAST decode's graph (parity tooling: scripts/flip_replay.py, tests/test_teacher_forced_gpu.py).  The host's graph
+// allocator never re-uses memory inside a graph, so every node a backend actually wrote is still there after the decode (run the plugin
+// with GGML_MI355X_NO_FUSION=1 to have every node written).  Handles stay valid until the model's next decode.
+EH_API void eh_model_force_layer_inputs(void * m, const float * const * rows, int n_layers) { Model * M = (Model *) m; M->forced_layer_inp.assign(rows, rows + n_layers); }
+EH_API void * eh_model_node(void * m, int i) { Model * M = (Model *) m; return (M->gctx && i >= 0 && i < (int) M->gctx->nodes.size()) ? M->gctx->nodes[i] : nullptr; }
+EH_API void eh_model_tensor_read(void * m, void * t, void * data, int64_t size) { ((Model *) m)->gctx->get((ggml_tensor *) t, data, 0, (size_t) size); }
 EH_API int eh_model_decode(void * mp, int n, const int32_t * tok, const int32_t * pos, const int32_t * seq, const uint8_t * lg, const float * hidd, int want_hidden) {
     Model * m = (Model *) mp; Batch b;
     for (int i = 0; i < n; ++i) b.add(tok[i], pos[i], seq ? seq[i] : 0, lg ? lg[i] != 0 : true);

@@ -341,6 +341,14 @@ void Model::build_forward(mh::Ctx & g, const StepIO & io, bool tp, std::vector<C
     int n_tok = io.T;
     for (int il = 0; il < cfg.n_layer; ++il) {
         const Layer & L = layers[il];
+        if (il > 0 && il < (int) forced_layer_inp.size() && forced_layer_inp[il]) {
+            // parity tooling (tests/test_teacher_forced_gpu.py): this layer reads a host-provided input (another backend's l_out of the
+            // layer below) instead of the graph's own, so that differences cannot compound across layers
+            ggml_tensor * f = g.new_tensor(GGML_TYPE_F32, cfg.n_embd, n_tok, 1, 1, "forced_inp");
+            f->flags |= GGML_TENSOR_FLAG_INPUT;
+            forced_tensors.push_back({ f, forced_layer_inp[il] });
+            inpL = f;
+        }
         ggml_tensor * inpSA = inpL;
         cur = g.rms_norm(inpL, cfg.rms_eps);
         if (L.attn_norm) cur = g.mul(cur, L.attn_norm);
@@ -448,6 +456,7 @@ int Model::decode_prepare(const Batch & b) {
     if (P.dev_tokens) embd = g.get_rows((ggml_tensor *) dev_table, (ggml_tensor *) dev_ids);      // llm_build_inp_embd's GET_ROWS branch (R/src/llama.cpp:495-503), indices already on the device
     StepIO io{ embd, P.inp_hidd, P.inp_pos, P.kq_mask, P.inp_out, T, n_outputs, n_kv, kv_head };
     P.result_norm = nullptr; P.result_output = nullptr; P.result_argmax = nullptr;
+    forced_tensors.clear();
     build_forward(g, io, P.tp, &P.cuts, P.result_norm, P.result_output, P.result_argmax);
     P.head_here = !P.tp || cfg.tp_rank == 0;                 // TP: the LM head (and the hidden-state channel) live on rank 0
     last_n_nodes = (int) g.nodes.size();
@@ -528,6 +537,8 @@ int Model::decode(const Batch & b, bool want_hidden) {
         flush(P.kq_mask, (char *) mask);
     }
     if (P.packed) g.set_async(P.base, stage_in, 0, P.span);
+    for (auto & f : forced_tensors) g.set_async(f.first, f.second, 0, mh::nbytes(f.first));      // (teacher forcing: valid for this decode only)
+    forced_layer_inp.clear();
     const double t2 = now_us();
 
     // ---- compute, then the outputs by asynchronous copies into page-locked memory, one wait for everything

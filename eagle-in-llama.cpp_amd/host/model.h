@@ -104,6 +104,9 @@ struct Model {
     // timing / stats
     double t_build_us = 0, t_upload_us = 0, t_compute_us = 0, t_download_us = 0; int64_t n_decode = 0;
     int last_n_nodes = 0;
+    // teacher forcing (parity tooling): host rows [T][n_embd] that layer il >= 1 of the NEXT decode reads instead of the layer below's output
+    std::vector<const float *> forced_layer_inp;
+    std::vector<std::pair<ggml_tensor *, const float *>> forced_tensors;
 
     static Model * create_synthetic(mh::Backend * be, const ModelConfig & cfg, const SynthOptions & opt, const Model * target /* for eagle */);
     ~Model();

@@ -3,10 +3,15 @@ shapes of BASELINE configs 4 (Llama-2-13B, TP = 2) and 5 (Llama-2-70B, TP = 8, G
 (oracle/_ref) running the same host graphs.
 
 Bound.  north_star asks for 1e-3 relative on verify logits.  Two IEEE-correct evaluations of this path differ in fp32 summation order;
-the int8 activation quantiser turns such an eps into flips of single quantised values, so the achievable agreement is what the
-reference's own AVX2 and scalar builds reach against each other on the same graph.  The test therefore (1) prints the measured GPU-vs-CPU
-and AVX2-vs-scalar figures (recorded in DESIGN.md 4), (2) asserts the GPU is at least as close to the reference as 4 x that spread, and
-(3) asserts the plain 1e-3 whenever the reference's own builds meet it."""
+the int8 activation quantiser turns such an eps into flips of single quantised values (counted node by node by scripts/flip_replay.py,
+profiles/r03_flip_replay_*.txt), so END TO END the achievable agreement is what the reference's own AVX2 and scalar builds reach against
+each other on the same graph.  The 1e-3 itself is asserted where it can hold -- per MUL_MAT and per layer, fed the reference's own inputs:
+tests/test_teacher_forced_gpu.py.  This test (1) prints the measured GPU-vs-CPU and AVX2-vs-scalar figures (recorded in DESIGN.md 4),
+(2) asserts the GPU is never further from the reference than 2 x the largest distance between the reference's two builds over the
+case's decodes, and (3) asserts the plain 1e-3 whenever the reference's own builds meet it.
+"The reference" has two answers here -- the same source built with and without AVX2 -- and neither is more correct than the other (the
+scalar branch is the ISA-independent definition, the AVX2 branch is what a default x86 build runs): the GPU's distance is taken to
+the nearer of the two, and both distances are printed."""
 import numpy as np
 import pytest
 
@@ -65,13 +70,13 @@ def test_layers_at_real_width_vs_reference_cpu(ea, gpu, case, capsys):
     for i, (x, y, z) in enumerate(zip(g, a, s)):
         assert x.shape == y.shape and np.isfinite(x).all()
         kind = "logits" if x.shape[-1] == dims[6] else "hidden"
-        rows.append((names[i], kind, min(l2rel(x, y), l2rel(x, z)), min(maxrel(x, y), maxrel(x, z)), l2rel(y, z), x, y))
+        rows.append((names[i], kind, min(l2rel(x, y), l2rel(x, z)), min(maxrel(x, y), maxrel(x, z)), l2rel(y, z), x, y, z))
     spread = max(r[4] for r in rows)
     with capsys.disabled():
-        for nm, kind, e_gpu, e_max, sp, _, _ in rows:
-            print(f"[width] {case} {nm} {kind}: gpu-vs-ref l2 {e_gpu:.2e} (max-rel {e_max:.2e}), ref avx2-vs-scalar l2 {sp:.2e}")
+        for nm, kind, e_gpu, e_max, sp, _x, _y, _z in rows:
+            print(f"[width] {case} {nm} {kind}: gpu-vs-ref l2 {e_gpu:.2e} (max-rel {e_max:.2e}; vs avx2 {l2rel(_x, _y):.2e}, vs scalar {l2rel(_x, _z):.2e}), ref avx2-vs-scalar l2 {sp:.2e}")
         print(f"[width] {case}: worst gpu-vs-ref {max(r[2] for r in rows):.2e}, worst ref-vs-ref {spread:.2e}")
-    for nm, kind, e_gpu, e_max, sp, x, y in rows:
+    for nm, kind, e_gpu, e_max, sp, x, y, _z in rows:
         assert e_gpu <= max(1e-3, 2.0 * spread), (case, nm, kind, e_gpu, spread)      # never further from the reference than its builds are from each other (x2)
         if kind == "logits":
             srt = np.sort(y, -1); clear = (srt[:, -1] - srt[:, -2]) > 0.05 * np.abs(y).max()
