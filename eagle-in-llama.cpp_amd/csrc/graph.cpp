@@ -194,7 +194,8 @@ static bool can_defer_norm(const gctx & c, int i) {
     const ggml_tensor * rms = c.g->nodes[i];
     const ggml_tensor * a = rms->src[0];
     if (!is_f32(a) || a->nb[0] != 4 || a->ne[2] != 1 || a->ne[3] != 1 || (a->nb[1] % 16) || ((uintptr_t) a->data % 16)) return false;
-    if (a->ne[1] > 24) return false;                                   // big batches: the norm runs on its own, the mat-muls take the one-pass kernel
+    // (more than 24 tokens: every reader is a big-batch launch of its own, and the norm is folded into the ONE quantiser launch that writes
+    //  the int8 image they share -- kernels_mmvq.hip k_quant_q8K / k_quant_q80, which also materialise the normalised tensor)
     // a norm the host will read back (graph output, "result_norm": the hidden-state channel) can still be folded when every reader is a
     // TILED launch: those write the normalised tensor as a side effect (kernels_mmt.hip, k_quant_q8K)
     bool wanted = (rms->flags & GGML_TENSOR_FLAG_OUTPUT) || name_is_result(rms);
@@ -256,6 +257,37 @@ static bool can_defer_concat(const gctx & c, int i) {
     const ggml_tensor * t = c.g->nodes[i + 1];
     if (t->op != GGML_OP_MUL_MAT || t->src[1] != x || !mi_mul_mat_q_supported_type(t->src[0]->type) || t->src[0]->ne[2] != 1 || t->src[0]->ne[3] != 1) return false;
     if (x->ne[2] != 1 || x->ne[3] != 1 || !mi_supports_op(0, t) || mi_tensor_is_split(t->src[0])) return false;
+    return true;
+}
+
+// SILU(gate) at node i -> MUL(silu, up) -> quantised mat-mul over >= 25 tokens (ffn_down of a prompt / wide verification batch): the two
+// element-wise nodes are left to the quantiser launch of that mat-mul, which reads gate and up in place and never writes the product.
+static bool can_defer_swiglu(const gctx & c, int i, int * mul_idx) {
+    const ggml_tensor * silu = c.g->nodes[i];
+    if (silu->op != GGML_OP_UNARY || mi_op_i32(silu, 0) != GGML_UNARY_OP_SILU || c.n_uses(silu) != 1 || (silu->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    const ggml_tensor * gate = silu->src[0];
+    const int im = c.last_use(silu);
+    const ggml_tensor * mul = c.g->nodes[im];
+    if (mul->op != GGML_OP_MUL || c.n_uses(mul) != 1 || (mul->flags & GGML_TENSOR_FLAG_OUTPUT) || !is_f32(mul) || !mi_is_contiguous(mul)) return false;
+    const ggml_tensor * up = mul->src[0] == silu ? mul->src[1] : (mul->src[1] == silu ? mul->src[0] : nullptr);
+    if (!up || up == silu || !is_f32(up) || !is_f32(gate) || !mi_is_contiguous(up) || !mi_is_contiguous(gate) || !mi_same_shape(up, mul) || !mi_same_shape(gate, mul)) return false;
+    if (mul->ne[2] != 1 || mul->ne[3] != 1 || mul->ne[1] <= 24 || (mul->ne[0] % 256) || ((uintptr_t) up->data % 16) || ((uintptr_t) gate->data % 16)) return false;
+    const int ir = c.last_use(mul);
+    const ggml_tensor * mm = c.g->nodes[ir];
+    if (mm->op != GGML_OP_MUL_MAT || mm->src[1] != mul || mm->src[0] == mul || !mi_mul_mat_q_supported_type(mm->src[0]->type) || mm->src[0]->ne[2] != 1 || mm->src[0]->ne[3] != 1) return false;
+    if (!mi_supports_op(0, mm) || mi_tensor_is_split(mm->src[0]) || !mi_ensure_tiled(mm->src[0])) return false;
+    // gate dies at the SILU, up at the MUL as far as the allocator knows: nothing that still runs before the mat-mul may write into them,
+    // and the mat-mul's own output (or the ADD folded behind it) must not land on them either (token passes re-read them)
+    const int iu = c.idx(up);                                          // (up is usually computed AFTER the SILU node: gate, silu, up, mul in DFS order)
+    for (int j = i + 1; j <= ir + 1 && j < c.n; ++j) {
+        if (j == im) continue;
+        const ggml_tensor * t = c.g->nodes[j];
+        if (j == ir + 1 && !(t->op == GGML_OP_ADD && (t->src[0] == mm || t->src[1] == mm))) break;
+        if (is_view_op(t->op)) continue;
+        if (overlap(gate->data, mi_nbytes(gate), t->data, mi_nbytes(t))) return false;
+        if (j > iu && overlap(up->data, mi_nbytes(up), t->data, mi_nbytes(t))) return false;
+    }
+    *mul_idx = im;
     return true;
 }
 
@@ -371,7 +403,23 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
             if      (nx->src[0] == t && is_f32(nx->src[1]) && mi_same_shape(nx->src[1], t) && nx->src[1]->nb[0] == 4) res = nx->src[1];
             else if (nx->src[1] == t && is_f32(nx->src[0]) && mi_same_shape(nx->src[0], t) && nx->src[0]->nb[0] == 4) res = nx->src[0];
         }
-        if (res) { mi_op_mul_mat_q(st, t, res, nx, ctx->act_cache); c.done[i + 1] = 1; } else mi_op_mul_mat_q(st, t, nullptr, t, ctx->act_cache);
+        // activation source other than x itself: a norm or a SwiGLU product left to this mat-mul's quantiser launch (big batches, fuse on)
+        act_src as{}; const act_src * asp = nullptr; const void * key = nullptr;
+        if (fuse && simple2d && big) {
+            act_plan ap; plan_act(c, x, (int) w0->ne[0], 1, i, ap);
+            const int ix = c.idx(x);
+            if (ap.rms) {
+                MI_ASSERT(mi_ensure_tiled(t->src[0]));
+                as = ap.src; as.norm_out = (float *) x->data; as.norm_os = x->nb[1]/4; asp = &as; key = ap.rms;
+                if (res && overlap(nx->data, mi_nbytes(nx), x->data, mi_nbytes(x))) as.norm_out = nullptr;      // that memory has been handed on: nobody reads the norm any more
+            } else if (x->op == GGML_OP_MUL && ix >= 0 && c.done[ix] == 2) {                                    // can_defer_swiglu
+                const ggml_tensor * silu = (x->src[0]->op == GGML_OP_UNARY && c.idx(x->src[0]) >= 0 && c.done[c.idx(x->src[0])] == 2) ? x->src[0] : x->src[1];
+                const ggml_tensor * up = x->src[0] == silu ? x->src[1] : x->src[0];
+                as = ap.src; as.X = (const float *) up->data; as.xs = up->nb[1]/4; as.G = (const float *) silu->src[0]->data; as.gs = silu->src[0]->nb[1]/4;
+                asp = &as; key = x;
+            }
+        }
+        if (res) { mi_op_mul_mat_q(st, t, res, nx, ctx->act_cache, asp, key); c.done[i + 1] = 1; } else mi_op_mul_mat_q(st, t, nullptr, t, ctx->act_cache, asp, key);
         return true;
     }
     const int k = (int) w0->ne[0], T = (int) x->ne[1];
@@ -600,6 +648,7 @@ enum ggml_status mi_graph_compute(mi_backend_ctx * ctx, ggml_cgraph * g) {
                 }
             } break;
             case GGML_OP_UNARY: {
+                { int im = -1; if (fuse && can_defer_swiglu(c, i, &im)) { c.done[i] = 2; c.done[im] = 2; break; } }
                 if (single_use && mi_op_i32(t, 0) == GGML_UNARY_OP_SILU && nx && nx->op == GGML_OP_MUL && is_f32(nx) && mi_is_contiguous(nx) && mi_same_shape(nx, t)) {
                     const ggml_tensor * other = nx->src[0] == t ? nx->src[1] : (nx->src[1] == t ? nx->src[0] : nullptr);
                     if (other && is_f32(other) && mi_is_contiguous(other) && mi_same_shape(other, t)) { mi_op_silu_mul(st, t->src[0], other, nx); c.done[i + 1] = 1; break; }

@@ -28,6 +28,7 @@ struct act_src {                        // activations of a mat-vec launch (see 
     const float * X; int64_t xs; const float * norm_w; int norm; float eps;
     const char * pre;                  // non-NULL: activations already quantised by mi_quant_act (image in HBM scratch)
     const float * X2; int64_t xs2; int ksplit;   // X2 non-NULL: the activations are CONCAT(X, X2) along k, X2 starting at element ksplit (EAGLE's [embd; hidd])
+    const float * G; int64_t gs;       // G non-NULL (quantiser launches of the big-batch path only): the activations are silu(G) * X, SwiGLU's product folded into ffn_down's quantiser
     float * norm_out; int64_t norm_os;  // with `norm`: where the folded RMS_NORM [* w] result is materialised as a side effect (row stride in floats); tiled kernel only
 };
 struct mmvq_mat {
@@ -74,7 +75,8 @@ double mi_launch_bytes(const mmvq_launch & L, int T, bool dual);
 int  mi_prof_begin(hipStream_t st, const mmvq_launch & L, int T, bool dual);
 void mi_prof_end(hipStream_t st, int idx);
 // quantised weight x f32 activations; residual (nullable) is added in the epilogue (fused ADD)
-void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out, mi_act_cache * cache);
+void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out, mi_act_cache * cache,
+                     const act_src * act = nullptr, const void * key = nullptr);      // act: activation source other than src1 itself (folded norm / SwiGLU product; 2-D operands only)
 // f16 / f32 / bf16 src0 x f32 src1 (attention K.q, V.p and unquantised weights)
 void mi_op_mul_mat_f(hipStream_t st, const ggml_tensor * dst);
 bool mi_mul_mat_q_supported_type(int type);

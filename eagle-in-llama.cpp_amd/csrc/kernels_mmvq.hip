@@ -354,6 +354,8 @@ __global__ void __launch_bounds__(NW*WAVE) k_quant_act(const act_src a, int k, c
         quant_q8K_to_lds<T, NW>(a, sc, k, q, d, bs, blockIdx.x*NW + wave, gridDim.x*NW, rec + (size_t) t0*nblk*32, rec + (size_t) Ttot*nblk*32 + (size_t) t0*nblk*32);
     } else quant_q80_to_lds<T, NW>(a, sc, k, q, d, blockIdx.x*NW + wave, gridDim.x*NW);
 }
+// ggml_silu_f32 (x / (1 + expf(-x))), the form kernels_ops.hip's silu_f and the SwiGLU epilogue of the tiled kernel use
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + expf(-x)); }
 // K-quant images, one wave per (token, super-block): with a folded RMS norm the wave sums the squares of ITS token row itself
 // (16 KB at k = 4096, all loads in flight at once) and keeps the four values of its own super-block from that pass, so there is a
 // single memory phase, no block barrier, and T*k/256 waves run in parallel (k_quant_act: every block first reduces all T rows).
@@ -389,6 +391,7 @@ __global__ void __launch_bounds__(512) k_quant_q8K(const act_src a, int k, char 
         } else {
             const int e = sb*256 + lane*4;
             v = (a.X2 && e >= a.ksplit) ? *(const float4 *)(a.X2 + (size_t) t*a.xs2 + (e - a.ksplit)) : *(const float4 *)(row + e);
+            if (a.G) { const float4 g = *(const float4 *)(a.G + (size_t) t*a.gs + e); v.x *= act_silu(g.x); v.y *= act_silu(g.y); v.z *= act_silu(g.z); v.w *= act_silu(g.w); }     // SwiGLU folded in: silu(gate) * up
         }
         quant_q8K_unit(v, lane, t, sb, k, nsb, q, d, bs, rec32, rec16);
     }
@@ -426,6 +429,7 @@ __global__ void __launch_bounds__(512) k_quant_q80(const act_src a, int k, char 
             }
         } else if (e < k) {
             v = (a.X2 && e >= a.ksplit) ? *(const float4 *)(a.X2 + (size_t) t*a.xs2 + (e - a.ksplit)) : *(const float4 *)(row + e);
+            if (a.G) { const float4 g = *(const float4 *)(a.G + (size_t) t*a.gs + e); v.x *= act_silu(g.x); v.y *= act_silu(g.y); v.z *= act_silu(g.z); v.w *= act_silu(g.w); }
         }
         q80_unit(v, q + (size_t) t*k + e, d + (size_t) t*nb + e/32, lane, e < k);
     }
@@ -721,7 +725,7 @@ void mi_mmvq_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_
 }
 
 // dst[rows, T, b2, b3] = W[k, rows, b2/r2, b3/r3] . X[k, T, b2, b3]   (+ residual)
-void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out, mi_act_cache * cache) {
+void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor * residual, const ggml_tensor * out, mi_act_cache * cache, const act_src * act, const void * key) {
     const ggml_tensor * w = dst->src[0], * x = dst->src[1];
     const int k = (int) w->ne[0], rows = (int) w->ne[1];
     const int64_t Ttot = x->ne[1];
@@ -736,6 +740,7 @@ void mi_op_mul_mat_q(hipStream_t st, const ggml_tensor * dst, const ggml_tensor 
         L.m[0].epi = EPI_F32; L.m[0].out = (char *) out->data + i2*out->nb[2] + i3*out->nb[3]; L.m[0].o_row = 4; L.m[0].o_tok = out->nb[1];
         if (residual) { L.m[0].res = (const float *)((const char *) residual->data + i2*residual->nb[2] + i3*residual->nb[3]); L.m[0].r_tok = residual->nb[1]/4; }
         L.tiled = mi_ensure_tiled((ggml_tensor *) w) ? 1 : 0;              // eligible weights are re-laid out at their first use (tile_layout.h)
-        mi_mmvq_run(st, w->type, (int) Ttot, L, cache, (x->ne[2] == 1 && x->ne[3] == 1) ? (const void *) x : nullptr);
+        if (act) { MI_ASSERT(x->ne[2] == 1 && x->ne[3] == 1 && L.tiled); L.act = *act; }
+        mi_mmvq_run(st, w->type, (int) Ttot, L, cache, key ? key : ((x->ne[2] == 1 && x->ne[3] == 1) ? (const void *) x : nullptr));
     }
 }

@@ -16,13 +16,13 @@ rng = np.random.default_rng(0)
 g = ea.Graph(gpu)
 outs = []; ins = []
 for i in range(12):            # independent attention sub-graphs, distinct caches
-    tq = g.tensor(ea.F32, d, H, T); tk = g.tensor(ea.F16, d, n_kv, H); tv = g.tensor(ea.F16, n_kv, d, H); tm = g.tensor(ea.F32, n_kv, 64)
+    tq = g.tensor(ea.F32, d, H, T); tk = g.tensor(ea.F16, d, n_kv, H); tv = g.tensor(ea.F16, n_kv, d, H); tm = g.tensor(ea.F32, n_kv, (T + 63) // 64 * 64)
     kqt = g.mul_mat(tk, g.permute(tq, 0, 2, 1, 3)); sm = g.soft_max(kqt, tm, 1.0 / np.sqrt(d))
     outs.append(g.cont(g.permute(g.mul_mat(tv, sm), 0, 2, 1, 3))); ins.append((tq, tk, tv, tm))
 g.alloc()
 for tq, tk, tv, tm in ins:
     g.set(tq, rng.standard_normal((T, H, d)).astype(np.float32)); g.set(tk, rng.standard_normal((H, n_kv, d)).astype(np.float16))
-    g.set(tv, rng.standard_normal((H, d, n_kv)).astype(np.float16)); g.set(tm, np.zeros((64, n_kv), np.float32))
+    g.set(tv, rng.standard_normal((H, d, n_kv)).astype(np.float16)); g.set(tm, np.zeros(((T + 63) // 64 * 64, n_kv), np.float32))
 g.compute(); g.compute()
 n = 512 * 4 * 8
 buf = (C.c_uint64 * n)(); assert lib.ggml_backend_mi355x_attn_stamps(buf) == n

@@ -87,7 +87,7 @@ static void write_model(const char * path, const dims & d, bool eagle, ggml_type
     gguf_free(g); ggml_free(ctx);
 }
 
-struct run_out { std::vector<float> prompt_logits, step_logits, tree_logits, draft_logits; std::vector<std::pair<std::string, std::vector<float>>> trace; };
+struct run_out { std::vector<float> prompt_logits, step_logits, tree_logits, long_logits, draft_logits; std::vector<std::pair<std::string, std::vector<float>>> trace; };
 
 // DROPIN_TRACE=1: record every f32 node of the first target decode through the scheduler's eval callback.
 // DROPIN_CUT=Qcur,ffn_gate: record only the nodes whose names start with one of the prefixes.  The reference scheduler then hands the
@@ -153,6 +153,14 @@ static bool run(const std::string & tgt_path, const std::string & dft_path, cons
     b.n_tokens = 0; add(40, 13, {1}, true); add(41, 14, {1}, true); add(50, 13, {2}, true); add(51, 14, {2}, true); add(52, 15, {2}, true);
     if (llama_decode(ct, b) != 0) return false;
     for (int i = 0; i < 5; ++i) { auto v = grab(ct, i, V); o.tree_logits.insert(o.tree_logits.end(), v.begin(), v.end()); }
+    // 3b. a 40-token batch on a fresh sequence: more than 24 tokens take the plugin's big-batch path (int8 GEMM over one shared activation
+    //     image, norm and SwiGLU product folded into the quantiser launches) -- here under the reference's allocator, which re-uses the
+    //     memory of gate / up / the norm input as soon as their last reader has run
+    b.n_tokens = 0;
+    for (int i = 0; i < 40; ++i) add(3 + (i * 11) % (V - 3), i, {3}, i >= 36);
+    if (llama_decode(ct, b) != 0) { fprintf(stderr, "llama_decode(long batch) failed\n"); return false; }
+    for (int i = 36; i < 40; ++i) { auto v = grab(ct, i, V); o.long_logits.insert(o.long_logits.end(), v.begin(), v.end()); }
+    llama_kv_cache_seq_rm(ct, 3, -1, -1);
     // 4. EAGLE channel: target step that hands result_norm to the draft, then two draft steps on the draft's own feature.
     //    The draft context first ingests a 12-token batch with plain llama_decode (as the tree driver does for the prompt):
     //    besides priming its KV cache this sizes its output buffer, without which the reference's hidden-state pointer
@@ -246,6 +254,7 @@ int main(int argc, char ** argv) {
     ok &= check("prompt", gpu.prompt_logits, cpu.prompt_logits, d.n_vocab, 5e-2);
     ok &= check("step", gpu.step_logits, cpu.step_logits, d.n_vocab, 5e-2);
     ok &= check("tree-verify", gpu.tree_logits, cpu.tree_logits, d.n_vocab, 5e-2);
+    ok &= check("batch-of-40", gpu.long_logits, cpu.long_logits, d.n_vocab, 5e-2);
     if (!getenv("DROPIN_CUT")) ok &= check("eagle-draft", gpu.draft_logits, cpu.draft_logits, d.n_vocab, 5e-2);
     printf(ok ? "DROP-IN OK\n" : "DROP-IN FAILED\n");
     remove(tp.c_str()); remove(dp.c_str());
