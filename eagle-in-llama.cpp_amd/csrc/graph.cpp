@@ -387,6 +387,37 @@ static void fill_mat(mmvq_mat & M, const member & m) {
     }
 }
 
+// Every layer of a forward pass rotates by the same positions: the {cos, sin} * attn_factor values for (token, pair) are computed once per
+// graph_compute (a 4 us launch; theta by the reference's float recurrence) instead of in every epilogue of every layer (up to 63 dependent
+// multiplies, then sinf / cosf: ~4 us per q|k|v launch at 6 tokens).  Built when the graph holds at least `min_users` ROPE nodes over these
+// positions and the root position tensor has at most `max_tokens` entries; returns the rows for `pos` (which may be a slice of a longer
+// tensor: the draft chain keeps the positions of all its steps in one input and hands every step a view) or NULL.
+static const float * rope_table_rows(mi_backend_ctx * ctx, const gctx & c, hipStream_t st, const mmvq_rope & R, const ggml_tensor * pos, int T, int64_t max_tokens, int min_users) {
+    static const bool tab_on = mi_lab_env("GGML_MI355X_NO_ROPE_TABLE") == nullptr;
+    mi_act_cache * ac = ctx->act_cache;
+    const ggml_tensor * root = pos->view_src ? pos->view_src : pos;
+    const int64_t poff = ((const char *) pos->data - (const char *) root->data) / 4, Troot = root->ne[0];
+    if (!(tab_on && Troot <= max_tokens && R.head_dim <= 256 && (R.head_dim % 2) == 0 && pos->type == GGML_TYPE_I32 && root->type == GGML_TYPE_I32 &&
+          root->nb[0] == 4 && mi_nrows(root) == 1 && poff >= 0 && poff + T <= Troot)) return nullptr;
+    const bool hit = ac->rope_tab && ac->rope_epoch == ac->epoch && ac->rope_pos == root->data && ac->rope_T == (int) Troot && ac->rope_hd == R.head_dim &&
+                     ac->rope_p[0] == R.theta_scale && ac->rope_p[1] == R.freq_scale && ac->rope_p[2] == R.attn_factor;
+    if (!hit) {
+        int users = 0;
+        for (int j = 0; j < c.n; ++j) { const ggml_tensor * r = c.g->nodes[j]; if (r->op == GGML_OP_ROPE && r->src[1] && (r->src[1] == root || r->src[1]->view_src == root)) users++; }
+        if (users < min_users) return nullptr;
+        const size_t need = (size_t) Troot * (R.head_dim / 2) * 2;
+        if (need > ac->rope_cap) {                                     // grows rarely (first prompt): launches already queued may still read the old table
+            if (ac->rope_tab) { HIP_CHECK(hipStreamSynchronize(st)); HIP_CHECK(hipFree(ac->rope_tab)); ac->rope_tab = nullptr; }
+            ac->rope_cap = need < (size_t) 24 * 128 * 2 ? (size_t) 24 * 128 * 2 : need + need / 2;
+            HIP_CHECK(hipMalloc((void **) &ac->rope_tab, ac->rope_cap * sizeof(float)));
+        }
+        mi_rope_table(st, (const int32_t *) root->data, (int) Troot, R.head_dim, R.theta_scale, R.freq_scale, R.attn_factor, ac->rope_tab);
+        ac->rope_epoch = ac->epoch; ac->rope_pos = root->data; ac->rope_T = (int) Troot; ac->rope_hd = R.head_dim;
+        ac->rope_p[0] = R.theta_scale; ac->rope_p[1] = R.freq_scale; ac->rope_p[2] = R.attn_factor;
+    }
+    return ac->rope_tab + (size_t) poff * (R.head_dim / 2) * 2;
+}
+
 // try to run MUL_MAT node i together with its siblings; returns true when handled
 static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
     ggml_tensor * t = c.g->nodes[i];
@@ -417,6 +448,39 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
                 const ggml_tensor * up = x->src[0] == silu ? x->src[1] : x->src[0];
                 as = ap.src; as.X = (const float *) up->data; as.xs = up->nb[1]/4; as.G = (const float *) silu->src[0]->data; as.gs = silu->src[0]->nb[1]/4;
                 asp = &as; key = x;
+            }
+        }
+        // epilogues of the one-pass GEMM (kernels_bb.hip): RoPE by table (q), RoPE -> f16 K-cache slice (k), transposed f16 V-cache store (v) --
+        // the four element-wise launches per layer a big batch used to carry behind q | k | v
+        if (fuse && simple2d && big && !res && mi_bb_supported(w0->type) && mi_ensure_tiled(t->src[0])) {
+            member m; m.node = i; m.mm = t; plan_member(c, m, false);
+            if (m.out != m.mm && (m.epi == EPI_F16 || m.epi == EPI_ROPE_F32 || m.epi == EPI_ROPE_F16)) {
+                const int T = (int) x->ne[1];
+                mmvq_launch L{};
+                if (asp) L.act = *asp; else { L.act.X = (const float *) x->data; L.act.xs = x->nb[1]/4; }
+                L.k = (int) w0->ne[0]; L.n_mat = 1; L.tiled = 1;
+                bool ok = true;
+                if (m.rope) {
+                    const ggml_tensor * pos = m.rope->src[1];
+                    L.rope.pos = (const int32_t *) pos->data; L.rope.head_dim = (int) m.rope->ne[0];
+                    L.rope.theta_scale = powf(mi_op_f32(m.rope, 5), -2.0f / mi_op_i32(m.rope, 1));
+                    L.rope.freq_scale = mi_op_f32(m.rope, 6); L.rope.attn_factor = mi_op_f32(m.rope, 8);
+                    L.rope.tab = rope_table_rows(ctx, c, st, L.rope, pos, T, 16384, 1);
+                    ok = L.rope.tab != nullptr && (w0->ne[1] % 2) == 0;
+                }
+                // the tail's buffer is written here instead of at its own node: nothing in between may still need that memory, and it must not
+                // be the activations' (a later token pass re-reads them)
+                std::vector<char> sk(c.n, 0); sk[i] = 1; for (int sidx : m.swallowed) sk[sidx] = 1;
+                const int orig = *std::max_element(m.swallowed.begin(), m.swallowed.end());
+                const size_t nb = mi_nbytes(m.out);
+                if (write_conflicts(c, m.out->data, nb, i, orig, sk) || overlap(m.out->data, nb, L.act.X, (size_t) T * L.act.xs * 4) ||
+                    (L.act.G && overlap(m.out->data, nb, L.act.G, (size_t) T * L.act.gs * 4)) || (L.act.norm_out && overlap(m.out->data, nb, x->data, mi_nbytes(x)))) ok = false;
+                if (ok) {
+                    fill_mat(L.m[0], m);
+                    mi_mmvq_run(st, w0->type, T, L, ctx->act_cache, key ? key : (const void *) x);
+                    for (int sidx : m.swallowed) c.done[sidx] = 1;
+                    return true;
+                }
             }
         }
         if (res) { mi_op_mul_mat_q(st, t, res, nx, ctx->act_cache, asp, key); c.done[i + 1] = 1; } else mi_op_mul_mat_q(st, t, nullptr, t, ctx->act_cache, asp, key);
@@ -519,33 +583,8 @@ static bool run_mmvq_group(mi_backend_ctx * ctx, gctx & c, int i, bool fuse) {
         L.rope.pos = (const int32_t *) pos->data; L.rope.head_dim = (int) rope0->ne[0];
         L.rope.theta_scale = powf(mi_op_f32(rope0, 5), -2.0f / mi_op_i32(rope0, 1));
         L.rope.freq_scale = mi_op_f32(rope0, 6); L.rope.attn_factor = mi_op_f32(rope0, 8);
-        L.rope.tab = nullptr;
-        // Every layer of a forward pass rotates by the same positions: when this graph holds at least four ROPE nodes (two layers) over these positions the
-        // {cos, sin} values are computed once (a 4 us launch) instead of in every epilogue of every layer (theta by a recurrence of up to 63
-        // dependent multiplies, then sinf / cosf: ~4 us per q|k|v launch at 6 tokens).  A chain step's single layer keeps the in-epilogue form.
-        static const bool tab_on = mi_lab_env("GGML_MI355X_NO_ROPE_TABLE") == nullptr;
-        mi_act_cache * ac = ctx->act_cache;
-        // positions may be a slice of a longer tensor (the draft chain keeps the positions of all its steps in one input and hands every step a
-        // view): the table covers the root, a launch reads its rows
-        const ggml_tensor * root = pos->view_src ? pos->view_src : pos;
-        const int64_t poff = ((const char *) pos->data - (const char *) root->data) / 4, Troot = root->ne[0];
-        if (tab_on && tiled0 && T <= 24 && Troot <= 24 && L.rope.head_dim <= 256 && (L.rope.head_dim % 2) == 0 && pos->type == GGML_TYPE_I32 && root->type == GGML_TYPE_I32 &&
-            root->nb[0] == 4 && mi_nrows(root) == 1 && poff >= 0 && poff + T <= Troot) {
-            const bool hit = ac->rope_epoch == ac->epoch && ac->rope_pos == root->data && ac->rope_T == (int) Troot && ac->rope_hd == L.rope.head_dim &&
-                             ac->rope_p[0] == L.rope.theta_scale && ac->rope_p[1] == L.rope.freq_scale && ac->rope_p[2] == L.rope.attn_factor;
-            const float * rows = ac->rope_tab + (size_t) poff * (L.rope.head_dim / 2) * 2;
-            if (!hit) {
-                int users = 0;
-                for (int j = 0; j < c.n; ++j) { const ggml_tensor * r = c.g->nodes[j]; if (r->op == GGML_OP_ROPE && r->src[1] && (r->src[1] == root || r->src[1]->view_src == root)) users++; }
-                if (users >= 4) {
-                    if (!ac->rope_tab) { HIP_CHECK(hipMalloc((void **) &ac->rope_tab, (size_t) 24 * 128 * 2 * sizeof(float))); rows = ac->rope_tab + (size_t) poff * (L.rope.head_dim / 2) * 2; }
-                    mi_rope_table(st, (const int32_t *) root->data, (int) Troot, L.rope.head_dim, L.rope.theta_scale, L.rope.freq_scale, L.rope.attn_factor, ac->rope_tab);
-                    ac->rope_epoch = ac->epoch; ac->rope_pos = root->data; ac->rope_T = (int) Troot; ac->rope_hd = L.rope.head_dim;
-                    ac->rope_p[0] = L.rope.theta_scale; ac->rope_p[1] = L.rope.freq_scale; ac->rope_p[2] = L.rope.attn_factor;
-                    L.rope.tab = rows;
-                }
-            } else L.rope.tab = rows;
-        }
+        // a chain step's single layer keeps the in-epilogue form (fewer than four ROPE nodes over these positions)
+        L.rope.tab = (tiled0 && T <= 24) ? rope_table_rows(ctx, c, st, L.rope, pos, T, 24, 4) : nullptr;
     }
     MI_ASSERT(tiled0 || !ap.rms);                                          // can_defer_norm: a fold needs tiled readers
     // a member whose (hoisted) output shares memory with the norm tensor: that memory has been handed on, nobody reads the norm any more

@@ -50,7 +50,7 @@ struct mi_act_cache {                  // quantised-activation images in HBM scr
     // whole-batch images of the big-batch kernel (k_mmt_bb): 4 x 8 MiB, allocated at first use
     char * big_pool = nullptr; int big_next = 0; entry big[4] = {};
     // RoPE table shared by the layers of one forward pass (graph.cpp): valid for `rope_epoch == epoch` and the key below
-    float * rope_tab = nullptr; uint64_t rope_epoch = 0; const void * rope_pos = nullptr; int rope_T = 0, rope_hd = 0; float rope_p[3] = {0, 0, 0};
+    float * rope_tab = nullptr; size_t rope_cap = 0 /* floats */; uint64_t rope_epoch = 0; const void * rope_pos = nullptr; int rope_T = 0, rope_hd = 0; float rope_p[3] = {0, 0, 0};
 };
 int  mi_mmvq_max_tokens(int type, int k);
 size_t mi_act_image_bytes(int type, int T, int k);

@@ -237,10 +237,28 @@ __global__ void __launch_bounds__(BB_WAVES*WAVE) k_bb(const mmvq_launch L, const
 #pragma unroll
         for (int s = 0; s < KS; ++s) v += red[((rt + RT*s)*16 + r)*64 + lane];
         const int tok = t0 + bb_tok_of(r, h);
-        if (tok < T && row < M.rows) {
-            if (M.res) v += M.res[(size_t) tok*M.r_tok + row];
-            if (M.relu) v = v > 0.f ? v : 0.f;
-            *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = v;
+        const bool act = tok < T && row < M.rows;
+        if (M.epi == EPI_F32) {
+            if (act) {
+                if (M.res) v += M.res[(size_t) tok*M.r_tok + row];
+                if (M.relu) v = v > 0.f ? v : 0.f;
+                *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = v;
+            }
+        } else if (M.epi == EPI_F16) {                                   // wv -> the transposed f16 V cache (the CPY node folded in)
+            if (act) *(__half *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = __float2half_rn(v);
+        } else {
+            // RoPE (mode NORM) on the row pair (2p, 2p + 1) = lanes l, l ^ 1, {cos, sin} from the table of this forward pass (graph.cpp) --
+            // the expressions of the tiled mat-vec's epilogue (kernels_mmt.hip) and of k_rope
+            const float pr = __shfl_xor(v, 1);
+            if (act) {
+                const int ip = (row % L.rope.head_dim) >> 1;
+                const float2 cs = *(const float2 *)(L.rope.tab + ((size_t) tok * (L.rope.head_dim >> 1) + ip) * 2);
+                const float c = cs.x, sn = cs.y;
+                const float x0 = (row & 1) ? pr : v, x1 = (row & 1) ? v : pr;
+                const float y = (row & 1) ? x0*sn + x1*c : x0*c - x1*sn;
+                if (M.epi == EPI_ROPE_F32) *(float *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = y;
+                else                       *(__half *)(M.out + (size_t) row*M.o_row + (size_t) tok*M.o_tok) = __float2half_rn(y);
+            }
         }
     }
 }
@@ -252,7 +270,8 @@ template <int TYPE> static size_t bb_lds() {
     return stage > red ? stage : red;
 }
 template <int TYPE> static void bb_launch(hipStream_t st, int T, const mmvq_launch & L) {
-    MI_ASSERT(L.act.pre && L.n_mat == 1 && L.m[0].rows % 16 == 0 && L.k % 256 == 0 && L.m[0].epi == EPI_F32 && !L.m[0].ids);
+    MI_ASSERT(L.act.pre && L.n_mat == 1 && L.m[0].rows % 16 == 0 && L.k % 256 == 0 && !L.m[0].ids);
+    MI_ASSERT(L.m[0].epi == EPI_F32 || L.m[0].epi == EPI_F16 || (L.rope.tab && L.rope.head_dim > 0 && L.rope.head_dim % 2 == 0 && L.m[0].rows % 2 == 0));
     const int nq = (T + 31) / 32, rows = L.m[0].rows;
     static const int cus = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256; return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256; }();
     // two row tiles per block (4-way split-K) when that still fills the chip, else one (8-way)

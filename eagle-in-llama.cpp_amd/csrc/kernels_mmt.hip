@@ -804,10 +804,14 @@ void mi_mmt_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_a
     // k too long for the LDS image at the wanted tokens per pass (ffn_down at > 8 tokens, k = 28672 at >= 5 tokens): k-chunks of whole
     // units, every later chunk adding to the output through the residual input.  Plain outputs only (the row norm needs the whole row).
     const int Tw = Ttot >= 24 ? 24 : (Ttot >= 16 ? 16 : (Ttot > 8 ? 8 : Ttot));
-    const bool plain_bb = L0.n_mat == 1 && !swiglu && L0.m[0].epi == EPI_F32 && !L0.m[0].relu && !L0.m[0].ids && !L0.act.X2;     // (the image's quantiser launch takes a folded norm / SwiGLU product)
-    const bool plain = plain_bb && !L0.act.norm && !L0.act.G;
-    MI_ASSERT(!L0.act.G || (plain_bb && Ttot >= mmt_bb_min_tokens()));       // silu(G) * X exists in the quantiser launches only (graph.cpp: can_defer_swiglu)
-    if (plain_bb && Ttot >= mmt_bb_min_tokens()) {
+    // the one-pass big-batch kernel: one matrix, any epilogue but the row selection; RoPE epilogues need the table (graph.cpp builds it for
+    // batches of any size); the image's quantiser launch takes a folded norm / SwiGLU product
+    const bool rope_epi = L0.n_mat == 1 && (L0.m[0].epi == EPI_ROPE_F32 || L0.m[0].epi == EPI_ROPE_F16);
+    const bool plain_bb = L0.n_mat == 1 && !swiglu && !L0.m[0].relu && !L0.m[0].ids && !L0.act.X2 && (!rope_epi || L0.rope.tab) && mi_bb_supported(type);
+    const bool old_ok = L0.n_mat == 1 && !swiglu && L0.m[0].epi == EPI_F32 && !L0.m[0].relu && !L0.m[0].ids && !L0.act.X2;      // round 2's kernel (Q4_0): plain f32 outputs only
+    const bool plain = old_ok && !L0.act.norm && !L0.act.G;
+    MI_ASSERT(!L0.act.G || ((plain_bb || old_ok) && Ttot >= mmt_bb_min_tokens()));       // silu(G) * X exists in the quantiser launches only (graph.cpp: can_defer_swiglu)
+    if ((plain_bb || old_ok) && Ttot >= mmt_bb_min_tokens()) {
         // one pass over the weights for the whole batch (a3); token passes only when the batch's int8 image outgrows a scratch slot
         int tpass = Ttot;
         while (tpass > 32 && mi_act_image_bytes(type, tpass, L0.k) > MI_BIG_SLOT_BYTES) tpass = (tpass / 2 + 31) / 32 * 32;
@@ -819,8 +823,9 @@ void mi_mmt_run(hipStream_t st, int type, int Ttot, const mmvq_launch & L0, mi_a
             if (L.act.norm_out) L.act.norm_out += (size_t) t0 * L.act.norm_os;
             L.m[0].out += (size_t) t0 * L.m[0].o_tok;
             if (L.m[0].res) L.m[0].res += (size_t) t0 * L.m[0].r_tok;
+            if (L.rope.tab) L.rope.tab += (size_t) t0 * (L.rope.head_dim >> 1) * 2;
             L.act.pre = mmt_big_image(st, type, T, t0, L, cache, key);
-            if (mi_bb_supported(type)) mi_bb_run(st, type, T, L); else mmt_bb_dispatch(st, type, T, L);      // (Q4_0, GGML_MI355X_BB_OLD=1: round 2's kernel)
+            if (plain_bb) mi_bb_run(st, type, T, L); else mmt_bb_dispatch(st, type, T, L);      // (Q4_0, GGML_MI355X_BB_OLD=1: round 2's kernel)
         }
         return;
     }
