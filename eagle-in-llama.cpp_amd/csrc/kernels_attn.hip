@@ -275,8 +275,11 @@ void mi_op_attn_small(hipStream_t st, const mi_attn_args & a) {
     const int tiles = (a.T + tt - 1) / tt;
     const int ntile = a.d / 16;                                   // output tiles of 16 head dims
     // more blocks when heads x token tiles under-fill the chip; a block keeps 1, 2 or 4 output tiles
-    int dsplit = (a.H * tiles >= 256) ? ntile/4 : ((a.H * tiles >= 128) ? ntile/2 : ntile);
+    // (160 (head, tile) pairs of a 69-token verification batch: 2 x 160 blocks run 7.7 ms per round, 4 x 160 blocks 8.0, 8 x 160 blocks 8.4 -- every
+    //  extra split recomputes K.q and the soft-max of its tile: profiles/r03_attn_dsplit_ab.txt)
+    int dsplit = (a.H * tiles >= 128) ? ntile/4 : ntile;
     if (dsplit < 1) dsplit = 1;
+    { static const int force = [] { const char * e = mi_lab_env("GGML_MI355X_ATTN_DSPLIT"); return e ? atoi(e) : 0; }(); if (force >= ntile/4 && force <= ntile && a.T > 8 && ntile % force == 0) dsplit = force; }      // lab A/B (big batches)
     const dim3 grid(a.H, tiles, dsplit);
 #ifdef MI_LAB
     if (a.d == 128 && attn_stamps_on()) {
