@@ -194,21 +194,24 @@ __global__ void __launch_bounds__(BB_WAVES*WAVE) k_bb(const mmvq_launch L, const
     float facc[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) facc[r] = 0.f;
+    const char * tbase = (n & 16) ? tp1 : tp0;
+    bb_w<TYPE> Wn; if (ks < nun) Wn.load(tbase + (size_t) ks * TILE, n & 15, h);
     for (int u = ks; u < nun; u += KS) {
         // ---- stage the unit's activations: 32 tokens x 256 bytes as 16-byte pieces (lane -> token (l >> 4) + 4 i, piece l & 15), scales, records
-        const char * tile = ((n & 16) ? tp1 : tp0) + (size_t) u * TILE;
-        bb_w<TYPE> W; W.load(tile, n & 15, h);                          // weights first: the longest round trip of the iteration
+        const char * tile = tbase + (size_t) u * TILE;
+        const bb_w<TYPE> W = Wn;                                         // requested one iteration ago
         i32x4 av[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const int tok = t0 + (lane >> 4) + 4*i; av[i] = tok < T ? *(const i32x4 *)(img + (size_t) tok*k + u*256 + 16*(lane & 15)) : (i32x4)(0); }
+        for (int i = 0; i < 8; ++i) { const int tok = min(t0 + (lane >> 4) + 4*i, T - 1); av[i] = *(const i32x4 *)(img + (size_t) tok*k + u*256 + 16*(lane & 15)); }      // (token slots past the batch read the last token: their results are never stored, and a clamp is no branch)
         float dyv[Q80 ? 4 : 1]; i32x4 rv = {0, 0, 0, 0};
         if constexpr (Q80) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const int c = lane + 64*i, tok = t0 + (c & 31), j = c >> 5; dyv[i] = tok < T ? img_d[(size_t) tok*nsb_img + u*8 + j] : 0.f; }
+            for (int i = 0; i < 4; ++i) { const int c = lane + 64*i, tok = min(t0 + (c & 31), T - 1), j = c >> 5; dyv[i] = img_d[(size_t) tok*nsb_img + u*8 + j]; }
         } else {
-            { const int tok = t0 + (lane & 31); dyv[0] = (lane < 32 && tok < T) ? img_d[(size_t) tok*nsb_img + u] : 0.f; }
-            { const int tok = t0 + (lane >> 1); if (tok < T) rv = ld16(img_rec + ((size_t) tok*nsb_img + u)*32 + 16*(lane & 1)); }
+            { const int tok = min(t0 + (lane & 31), T - 1); dyv[0] = img_d[(size_t) tok*nsb_img + u]; }
+            { const int tok = min(t0 + (lane >> 1), T - 1); rv = ld16(img_rec + ((size_t) tok*nsb_img + u)*32 + 16*(lane & 1)); }
         }
+        if (u + KS < nun) Wn.load(tbase + (size_t)(u + KS) * TILE, n & 15, h);      // the NEXT unit's weights go out behind this unit's activations (vmcnt retires in order: waiting for the activations leaves these in flight)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous unit's fragment reads are done (wave-private buffer: no barrier)
 #pragma unroll
         for (int i = 0; i < 8; ++i) *(i32x4 *)(abuf + ((lane >> 4) + 4*i)*BB_LD + 16*(lane & 15)) = av[i];
