@@ -280,6 +280,7 @@ void mi_op_attn_small(hipStream_t st, const mi_attn_args & a) {
     int dsplit = (a.H * tiles >= 128) ? ntile/4 : ntile;
     if (dsplit < 1) dsplit = 1;
     { static const int force = [] { const char * e = mi_lab_env("GGML_MI355X_ATTN_DSPLIT"); return e ? atoi(e) : 0; }(); if (force >= ntile/4 && force <= ntile && a.T > 8 && ntile % force == 0) dsplit = force; }      // lab A/B (big batches)
+    { static const int force = [] { const char * e = mi_lab_env("GGML_MI355X_ATTN_DSPLIT_SMALL"); return e ? atoi(e) : 0; }(); if (force >= ntile/4 && force <= ntile && a.T <= 8 && ntile % force == 0) dsplit = force; }      // lab A/B (<= 8 tokens)
     const dim3 grid(a.H, tiles, dsplit);
 #ifdef MI_LAB
     if (a.d == 128 && attn_stamps_on()) {
