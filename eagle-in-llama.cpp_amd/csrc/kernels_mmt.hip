@@ -90,19 +90,43 @@ __device__ __forceinline__ int pack_b0(const i32x4 b) {
 template <bool Q80, int LG> __device__ __forceinline__ constexpr int mt_eoff(int i) { return Q80 ? 4*i : 4*LG*i; }
 template <bool Q80, int LG> __device__ __forceinline__ int mt_poff(int p) { return Q80 ? (256/LG)*p : 4*p; }
 
+// cross-lane integer maxima over the LG lanes of a token group (result in every lane of the group)
+template <int LG> __device__ __forceinline__ int grp_max_i(int v) {
+    v = max(v, dpp_i<DPP_XOR1>(v)); v = max(v, dpp_i<DPP_XOR2>(v)); v = max(v, dpp_i<DPP_HMIR>(v));
+    if (LG >= 16) v = max(v, dpp_i<DPP_MIR>(v));
+    if (LG >= 32) { uint32_t a, b; lane_pair<16>((uint32_t) v, a, b); v = max((int) a, (int) b); }
+    if (LG >= 64) { uint32_t a, b; lane_pair<32>((uint32_t) v, a, b); v = max((int) a, (int) b); }
+    return v;
+}
+template <int LG> __device__ __forceinline__ uint32_t grp_max_u(uint32_t v) {
+    v = max(v, (uint32_t) dpp_i<DPP_XOR1>((int) v)); v = max(v, (uint32_t) dpp_i<DPP_XOR2>((int) v)); v = max(v, (uint32_t) dpp_i<DPP_HMIR>((int) v));
+    if (LG >= 16) v = max(v, (uint32_t) dpp_i<DPP_MIR>((int) v));
+    if (LG >= 32) { uint32_t a, b; lane_pair<16>(v, a, b); v = max(a, b); }
+    if (LG >= 64) { uint32_t a, b; lane_pair<32>(v, a, b); v = max(a, b); }
+    return v;
+}
+// One super-block of every token slot of the wave -> int8 image, scales, split block sums.  Round 3 (the one positive result of the mat-vec
+// lab, profiles/r03_matvec_lab_findings.md: -5..7 % on the launches without a norm): the signed extrema are tracked on the INTEGER pipe -- a
+// non-negative float orders like its bit pattern, among negative floats the unsigned order is the magnitude order: v_max3_i32 / v_max3_u32, no NaN
+// canonicalisation, single DPP-fused cross-lane steps -- and the block sums are not reduced across lanes (24 DPP adds per super-block) but read
+// back: the wave's own int8 bytes, 32 consecutive per lane, summed with v_dot4 by one lane per (token, 32-group).
 template <int TYPE, int LG>
-__device__ __forceinline__ void mt_quant_sb(const f32x4v (&x)[64/LG], const bool tv, const int t, const int p, const int sb, const int ldq, const int nsb, int8_t * lq, float * ldy, char * lrec) {
+__device__ __forceinline__ void mt_quant_sb(const f32x4v (&x)[64/LG], const bool tv, const int t, const int p, const int T, const int sb, const int ldq, const int nsb, int8_t * lq, float * ldy, char * lrec) {
     constexpr bool Q80 = TYPE == GGML_TYPE_Q8_0 || TYPE == GGML_TYPE_Q4_0;
     constexpr int NF = 64/LG;
     int8_t * dst = lq + (size_t) t*ldq + sb*256 + mt_poff<Q80, LG>(p);
     if constexpr (Q80) {
-        // LG/8 consecutive lanes share a 32-element block: d = amax/127, id = 1/d, q = roundf(x*id), d kept through fp16
-        float amax = 0.f;
+        // LG/8 consecutive lanes share a 32-element block: d = amax/127, id = 1/d, q = roundf(x*id), d kept through fp16 (quantize_row_q8_0_ref)
+        int am = 0;
 #pragma unroll
-        for (int i = 0; i < NF; ++i) { amax = max3af(x[i].x, x[i].y, amax); amax = max3af(x[i].z, x[i].w, amax); }
-        if (LG >= 16) amax = fmaxf(amax, dpp_f<DPP_XOR1>(amax));
-        if (LG >= 32) amax = fmaxf(amax, dpp_f<DPP_XOR2>(amax));
-        if (LG >= 64) amax = fmaxf(amax, dpp_f<DPP_HMIR>(amax));
+        for (int i = 0; i < NF; ++i) {
+            const i32x4 b = __builtin_bit_cast(i32x4, x[i]) & 0x7fffffff;
+            am = max(max(b.x, b.y), am); am = max(max(b.z, b.w), am);
+        }
+        if (LG >= 16) am = max(am, dpp_i<DPP_XOR1>(am));
+        if (LG >= 32) am = max(am, dpp_i<DPP_XOR2>(am));
+        if (LG >= 64) am = max(am, dpp_i<DPP_HMIR>(am));
+        const float amax = __int_as_float(am);
         const float dd = amax / 127.f;
         const float id = dd ? 1.0f/dd : 0.0f;
 #pragma unroll
@@ -113,16 +137,21 @@ __device__ __forceinline__ void mt_quant_sb(const f32x4v (&x)[64/LG], const bool
         }
         if (tv && (p % (LG/8)) == 0) ldy[t*nsb + sb*8 + p / (LG/8)] = __half2float(__float2half_rn(dd));
     } else {
-        float pm = 0.f, nm = 0.f;
+        // Q8_K rule (quantize_row_q8_K_ref): the scale comes from the FIRST element of largest magnitude.  pmb = bits of max(+x) (signed integer
+        // order, floor +0), nmb = bits of the most negative element (unsigned order, floor -0)
+        int pmb = 0; uint32_t nmb = 0x80000000u;
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
-            pm = max3f(x[i].x, x[i].y, pm);  pm = max3f(x[i].z, x[i].w, pm);
-            nm = max3nf(x[i].x, x[i].y, nm); nm = max3nf(x[i].z, x[i].w, nm);
+            const i32x4 b = __builtin_bit_cast(i32x4, x[i]);
+            pmb = max(max(b.x, b.y), pmb); pmb = max(max(b.z, b.w), pmb);
+            nmb = max(max((uint32_t) b.x, (uint32_t) b.y), nmb); nmb = max(max((uint32_t) b.z, (uint32_t) b.w), nmb);
         }
-        pm = grp_max_f<LG>(pm); nm = grp_max_f<LG>(nm);
-        const float amax = fmaxf(pm, nm);
-        float mx = pm > nm ? pm : -nm;
-        const bool tie = pm == nm && amax != 0.f;
+        pmb = grp_max_i<LG>(pmb); nmb = grp_max_u<LG>(nmb);
+        const int nmag = (int)(nmb & 0x7fffffffu);
+        const float pm = __int_as_float(pmb), nm = __int_as_float(nmag);
+        const float amax = pmb > nmag ? pm : nm;
+        float mx = pmb > nmag ? pm : -nm;
+        const bool tie = pmb == nmag && pmb != 0;
         if (__any(tie)) {      // a positive and a negative element share the largest magnitude: the first one in element order decides
             int key = 0x7fffffff;
 #pragma unroll
@@ -134,10 +163,9 @@ __device__ __forceinline__ void mt_quant_sb(const f32x4v (&x)[64/LG], const bool
             key = grp_min_i<LG>(key);
             if (tie) mx = (key & 1) ? -amax : amax;
         }
-        const bool nz = amax != 0.f;
+        const bool nz = pmb != 0 || nmag != 0;
         const float iscale = nz ? -127.f / mx : 0.f;
         const float dd = nz ? 1.0f / iscale : 0.f;
-        int s4[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) {
             f32x4v r;
@@ -147,38 +175,24 @@ __device__ __forceinline__ void mt_quant_sb(const f32x4v (&x)[64/LG], const bool
                 r = m + 12582912.f;
             }
             const int pk = pack_b0(__builtin_bit_cast(i32x4, r));
-            s4[i] = dot4(pk, 0x01010101, 0);
             if (tv) *(int *)(dst + 4*LG*i) = pk;
         }
         if (tv && p == 0) ldy[t*nsb + sb] = dd;
-        // block sums for the mins / offset MFMA, split as s = 128 h + l (mmvq_device.h): float4 f = p + LG i lies in 16-group f >> 2 and 32-group f >> 3
-        if constexpr (TYPE == GGML_TYPE_Q6_K) {     // rec16: [l0..l15, h0..h15]
-            int8_t * r16 = (int8_t *) lrec + (size_t)(t*nsb + sb)*32;
-#pragma unroll
-            for (int i = 0; i < NF; ++i) {
-                int s = s4[i]; s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s);
-                const int g = (p >> 2) + (LG/4)*i;
-                if (tv && (p & 3) == 0) { r16[g] = (int8_t)(s & 127); r16[16 + g] = (int8_t)(s >> 7); }
-            }
-        } else {                                    // rec32: [l0..l7, 0 x 8, h0..h7, 0 x 8]
-            int8_t * r32 = (int8_t *) lrec + (size_t)(t*nsb + sb)*32;
-            if constexpr (LG == 8) {                 // lane p == 0 ends up with all eight sums: one record = two 16-byte stores
-                uint32_t l0 = 0, l1 = 0, h0 = 0, h1 = 0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int s = s4[i]; s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s); s += dpp_i<DPP_HMIR>(s);
-                    const uint32_t lb = (uint32_t)(s & 127), hb = (uint32_t)((s >> 7) & 0xff);
-                    if (i < 4) { l0 |= lb << (8*i); h0 |= hb << (8*i); } else { l1 |= lb << (8*(i - 4)); h1 |= hb << (8*(i - 4)); }
-                }
-                if (tv && p == 0) { ((i32x4 *) r32)[0] = (i32x4){ (int) l0, (int) l1, 0, 0 }; ((i32x4 *) r32)[1] = (i32x4){ (int) h0, (int) h1, 0, 0 }; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NF; ++i) {
-                    int s = s4[i]; s += dpp_i<DPP_XOR1>(s); s += dpp_i<DPP_XOR2>(s); s += dpp_i<DPP_HMIR>(s);
-                    const int g = (p >> 3) + (LG/8)*i;
-                    if (tv && (p & 7) == 0) { r32[g] = (int8_t)(s & 127); r32[16 + g] = (int8_t)(s >> 7); }
-                    if (tv && (p & 7) == 4) { r32[8 + g] = 0; r32[24 + g] = 0; }
-                }
+        // block sums for the mins / offset MFMA, split as s = 128 h + l (mmvq_device.h): the wave reads its own bytes back (LDS is in order per
+        // wave), lane (token tt, 32-group g) sums 32 consecutive int8 with dot4; 8 * 64/LG lanes take part
+        const int lane = t*LG + p, tt = lane >> 3, g = lane & 7;
+        if (tt < 64/LG && tt < T) {
+            const int8_t * src = lq + (size_t) tt*ldq + sb*256 + 32*g;
+            const i32x4 a0 = *(const i32x4 *) src, a1 = *(const i32x4 *)(src + 16);
+            const int s0 = dot16(a0, (i32x4)(0x01010101)), s1 = dot16(a1, (i32x4)(0x01010101));
+            int8_t * rec = (int8_t *) lrec + (size_t)(tt*nsb + sb)*32;
+            if constexpr (TYPE == GGML_TYPE_Q6_K) {     // rec16: [l0..l15, h0..h15], 16-element groups 2g, 2g + 1
+                *(uint16_t *)(rec + 2*g)      = (uint16_t)((s0 & 127) | ((s1 & 127) << 8));
+                *(uint16_t *)(rec + 16 + 2*g) = (uint16_t)(((s0 >> 7) & 0xff) | (((s1 >> 7) & 0xff) << 8));
+            } else {                                    // rec32: [l0..l7, 0 x 8, h0..h7, 0 x 8]
+                const int s = s0 + s1;
+                rec[g] = (int8_t)(s & 127); rec[16 + g] = (int8_t)(s >> 7);
+                if (g < 4) *(int *)(rec + 8 + 4*(g & 1) + 16*(g >> 1)) = 0;
             }
         }
     }
@@ -255,7 +269,7 @@ __device__ __forceinline__ void mt_norm_quant(const act_src & a, const int T, co
                 if (a.norm_out && blockIdx.x == 0 && tv) *(f32x4v *)(a.norm_out + (size_t) t*a.norm_os + e) = v;
                 xv[c][i] = v;
             }
-            mt_quant_sb<TYPE, LG>(xv[c], tv, t, p, sb, ldq, nsb, lq, ldy, lrec);
+            mt_quant_sb<TYPE, LG>(xv[c], tv, t, p, T, sb, ldq, nsb, lq, ldy, lrec);
         }
     }
 }
@@ -282,7 +296,7 @@ __device__ __forceinline__ void mt_quantise_lg(const act_src & a, const int T, c
         if (pfpos == 0) prefetch();
         for (int sb = wave; sb < nun; sb += 16) {
             if (sb != wave) mt_load_sb<TYPE, LG>(a, x, tv, t, p, sb);
-            mt_quant_sb<TYPE, LG>(x, tv, t, p, sb, ldq, nsb, lq, ldy, lrec);
+            mt_quant_sb<TYPE, LG>(x, tv, t, p, T, sb, ldq, nsb, lq, ldy, lrec);
             if (pfpos == 1 && sb == wave) prefetch();
         }
         if (pfpos >= 2 || (pfpos == 1 && wave >= nun)) prefetch();
