@@ -337,14 +337,14 @@ def main():
         # the reference's TREE driver (host/tree_driver.cpp): 4 branches forking on p_split, greedy verification
         try:
             # (the synthetic draft's best logit stands ~55 above the rest: a second candidate passes p_split only once the draft distribution
-            #  is flattened -- temperature 13 gives a few forks per round without throwing the chain's acceptance away)
-            ts = ea.TreeSession(tgt, dft, prompt, n_seq_dft=4, n_draft=7, p_split=0.02, temp=0.0, temp_dft=13.0, top_k=8)
+            #  is flattened -- temperature 13 gives a few forks per round without throwing the chain's acceptance away; draft-max 5 keeps the batch <= 9)
+            ts = ea.TreeSession(tgt, dft, prompt, n_seq_dft=4, n_draft=5, p_split=0.02, temp=0.0, temp_dft=13.0, top_k=8)
             ts.run(8)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             tt, tst = ts.run(96)
             torch.cuda.synchronize(); d1 = time.perf_counter() - t1
             ts.close()
-            extra["tree_driver"] = {"workload": "np 4, draft-max 7, p_split 0.02, draft temperature 13 (the synthetic draft is near one-hot: it forks only when flattened), top-k on the device, greedy verification", "tokens_per_s": round(len(tt) / d1, 1),
+            extra["tree_driver"] = {"workload": "np 4, draft-max 5, p_split 0.02, draft temperature 13 (the synthetic draft is near one-hot: it forks only when flattened; on this synthetic pair a fork is pure cost -- the second candidate is never the target's token -- the same driver without forks, temp_dft 10, draft-max 7, runs 1400 tokens/s: profiles/r03_tree_probe.txt), top-k on the device, greedy verification", "tokens_per_s": round(len(tt) / d1, 1),
                                     "tokens_per_round": round(tst["n_predict"] / max(1.0, tst["n_iters"]), 3), "forks": int(tst["n_forks"]), "max_verify_batch": int(tst["max_batch"]),
                                     "verify_ms_per_round": round(tst["t_verify_us"] / max(1.0, tst["n_iters"]) / 1e3, 3), "draft_ms_per_round": round(tst["t_draft_us"] / max(1.0, tst["n_iters"]) / 1e3, 3)}
         except Exception as e:
