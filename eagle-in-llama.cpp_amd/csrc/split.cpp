@@ -114,12 +114,13 @@ static bool peer_ok(int from, int to) {
     return state[from][to] > 0;
 }
 // events of one backend instance (a backend is used by one thread at a time): `ready` on its own device, done[d] on logical device d
-struct mi_split_events { hipEvent_t ready = nullptr; hipEvent_t done[SPLIT_MAX] = {}; };
+struct mi_split_events { hipEvent_t ready = nullptr, scattered = nullptr; hipEvent_t done[SPLIT_MAX] = {}; };
 static mi_split_events * events_of(mi_backend_ctx * ctx) {
     if (!ctx->split_ev) {
         mi_split_events * ev = new mi_split_events;
         HIP_CHECK(hipSetDevice(ctx->device));
         HIP_CHECK(hipEventCreateWithFlags(&ev->ready, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&ev->scattered, hipEventDisableTiming));
         ctx->split_ev = ev;
     }
     return ctx->split_ev;
@@ -128,6 +129,7 @@ void mi_split_free_events(mi_backend_ctx * ctx) {
     mi_split_events * ev = ctx->split_ev;
     if (!ev) return;
     if (ev->ready) HIP_CHECK(hipEventDestroy(ev->ready));
+    if (ev->scattered) HIP_CHECK(hipEventDestroy(ev->scattered));
     for (int d = 0; d < SPLIT_MAX; ++d) if (ev->done[d]) HIP_CHECK(hipEventDestroy(ev->done[d]));
     delete ev; ctx->split_ev = nullptr;
 }
@@ -292,4 +294,11 @@ void mi_split_mul_mat(mi_backend_ctx * ctx, const ggml_tensor * dst) {
     // dst[t][lo .. lo+n) <- hs[t][0 .. n): one 2-D copy per staged slice (reference :1631-1635), on the main device's own stream
     for (int i = 0; i < n_late; ++i)
         HIP_CHECK(hipMemcpy2DAsync((char *) dst->data + (size_t) late[i].lo * 4, dst->nb[1], g_sd[late[i].d].hs, (size_t) late[i].n * 4, (size_t) late[i].n * 4, T, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n_late) {
+        // the staging twins are re-used by the next MUL_MAT on these devices -- possibly issued through ANOTHER backend instance, whose stream is
+        // not ordered with this one: the devices' streams wait until the scatters above have read them
+        HIP_CHECK(hipEventRecord(ev->scattered, ctx->stream));
+        for (int i = 0; i < n_late; ++i) { split_dev & s = g_sd[late[i].d]; std::lock_guard<std::mutex> lk(s.mu); HIP_CHECK(hipSetDevice(phys(late[i].d))); HIP_CHECK(hipStreamWaitEvent(s.stream, ev->scattered, 0)); }
+        HIP_CHECK(hipSetDevice(home));
+    }
 }
