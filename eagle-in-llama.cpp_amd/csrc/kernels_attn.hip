@@ -15,6 +15,7 @@
 // rows: 8 consecutive cells of one head dim), the B fragment is the f16-rounded q / p row of token lane%16.  Scores
 // live in LDS (fp32), the f16 probabilities in a second LDS image; the soft-max keeps the CPU's double sum.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_fp16.h>
 #include "kernels.h"
 #include "mi355x_common.h"
@@ -144,10 +145,11 @@ template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_at
         if (t < nt) {
             float * row = sc + t*ldS;
             _Float16 * prow = ph + t*ldP;
-            constexpr int NR = 12;                              // scores per lane kept in registers: n_kv <= 12 lanes-per-token (384 cells at 32 lanes)
-            if (n_kv <= NR*lg) {
-                // one LDS read and one write per score instead of three round trips (max, exp, normalise passes over the LDS row): the
-                // phase is a latency chain at one wave per SIMD.  Same per-lane order of operations as the loop form below.
+            // one LDS read and one write per score instead of three round trips (max, exp, normalise passes over the LDS row): the
+            // phase is a latency chain at one wave per SIMD.  Same per-lane order of operations as the loop form below.  Scores per lane
+            // kept in registers: 12 at 32 lanes per token, 24 at 16 lanes per token (16-token tiles of big batches): n_kv <= 384 either way
+            auto in_regs = [&](auto nr_tag) {
+                constexpr int NR = decltype(nr_tag)::value;
                 float v[NR];
 #pragma unroll
                 for (int j = 0; j < NR; ++j) { const int i = sub + j*lg; v[j] = i < n_kv ? row[i] : -INFINITY; }
@@ -162,7 +164,10 @@ template <int D, bool STAMP = false> __global__ void __launch_bounds__(256) k_at
                 const float inv = (float)(1.0 / sum);
 #pragma unroll
                 for (int j = 0; j < NR; ++j) { const int i = sub + j*lg; if (i < n_kv) prow[i] = (_Float16)(v[j] * inv); }
-            } else {
+            };
+            if (lg == 32 && n_kv <= 12*32) in_regs(std::integral_constant<int, 12>{});
+            else if (lg == 16 && n_kv <= 24*16) in_regs(std::integral_constant<int, 24>{});
+            else {
             float mx = -INFINITY;
             for (int i = sub; i < n_kv; i += lg) mx = fmaxf(mx, row[i]);
             mx = row_max_f(mx); if (lg == 32) mx = max_xw<16>(mx);            // 16 or 32 lanes per token: DPP row steps + one VALU lane-pair step
