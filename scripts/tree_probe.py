@@ -16,3 +16,7 @@ t0 = time.perf_counter(); tt, st = ts.run(nt); d = time.perf_counter() - t0
 it = max(1.0, st["n_iters"])
 print(f"{ftype} np {np_} draft-max {nd} p_split {ps} temp_dft {td} top_k {tk}: {len(tt)/d:.1f} tokens/s, {st['n_predict']/it:.2f} tokens/round, forks {int(st['n_forks'])}, "
       f"max verify batch {int(st['max_batch'])}, draft {st['t_draft_us']/it/1e3:.2f} ms/round ({st['n_draft_calls']/it:.1f} decodes), verify {st['t_verify_us']/it/1e3:.2f} ms/round")
+for nm, m in (("draft", dft), ("target", tgt)):
+    t = m.timers()
+    n = max(1.0, t[4]) if not isinstance(t, dict) else max(1.0, t.get("n_decode", 1))
+    print(f"  {nm} model host timers per decode: {t}")
