@@ -51,6 +51,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "q8":          # Q8_0 shapes (config 3),
     for T in (1, 6, 24):
         for rows, k in ((4096, 4096), (11008, 4096), (4096, 11008)): run(8, rows, k, T, "plain")
     sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "tg":          # 8 tokens (one group, in-kernel quantiser) against 9 / 16 / 24 (token groups, image launch): the a2 path
+    for t in (12, 8):
+        for T in (8, 9, 16, 24):
+            for rows, k in ((4096, 4096), (4096, 11008), (32000, 4096)): run(t, rows, k, T, "single")
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "single":      # the model's single-matrix launches (wo, ffn_down, lm_head) at T = 6
     for t in (12, 14):
         for rows, k in ((4096, 4096), (4096, 11008), (32000, 4096)): run(t, rows, k, 6, "single")
